@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- 1-vs-N triples scored / s of the HIP scoring path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the whole hot path (query vectors + 1-vs-all scores + sigmoid)
+over one batch of synthetic (h, r) queries, operands already resident in HBM.
+N = 1 workload: BASELINE.json configs[1] -- WN18RR asymmetric rank (10,200,200),
+batch 512, fp32, 40 943 entities, 22 relations.  N > 1: the entity matrix O is
+row-sharded over the ranks and the per-shard score blocks are all-gathered with RCCL
+(north_star); every rank scores the same batch against its shard.
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline`
+for the dominant kernel (the score kernel, timed with HIP events on its own stream
+inside the timed region) and `cpu_baseline` (the oracle's restatement of the reference
+op sequence timed on the host cores; N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import gen  # noqa: E402
+
+WORKLOADS = {
+    # name: (n_ent, n_rel, batch, rank, dtype)
+    "wn18rr_asym_r10x200_b512_f32": (40943, 22, 512, (10, 200, 200), "f32"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(n_ent, n_rel, B, rank, pool, budget_s=12.0):
+    """The oracle (CPU restatement of the reference's five torch ops) on the host cores."""
+    from oracle import score_oracle as orc
+    core, R, S, O = [torch.from_numpy(x) for x in gen.make_params(n_ent, n_rel, rank, 322)]
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        for i in range(3):
+            orc.score_ref(core, R, S, O, pool[i][0], pool[i][1])
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget_s:
+            h, r = pool[n % len(pool)]
+            orc.score_ref(core, R, S, O, h, r)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": n * B / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{n} batches of {B} queries ({dt:.1f} s) of the same workload, torch {torch.__version__} CPU fp32, "
+                      f"{threads} threads; oracle/score_oracle.py::score_ref"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="wn18rr_asym_r10x200_b512_f32", choices=sorted(WORKLOADS))
+    ap.add_argument("--exact", action="store_true", help="exact-fp32 MFMA score kernel instead of split-fp16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import r_tucker_amd as rt
+    from r_tucker_amd import _lib
+    lib = _lib.load()
+
+    n_ent, n_rel, B, trank, dtype = WORKLOADS[args.workload]
+    a, b, c = trank
+    core, R, S, O = [torch.from_numpy(x).to(dev) for x in gen.make_params(n_ent, n_rel, trank, 322)]
+    pool_cpu = [tuple(torch.from_numpy(x) for x in gen.make_queries(n_ent, n_rel, B, 1000 + i)) for i in range(64)]
+    pool = [(h.to(dev), r.to(dev)) for h, r in pool_cpu]
+
+    # entity shard of this rank (row block of O); N = 1: the whole matrix
+    n_loc = -(-n_ent // world)
+    lo = min(rank * n_loc, n_ent)
+    hi = min(lo + n_loc, n_ent)
+    O_loc = torch.zeros((n_loc, c), dtype=torch.float32, device=dev)
+    O_loc[: hi - lo] = O[lo:hi]                       # last shard zero-padded to equal size
+    out = torch.empty((B, n_loc), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, B, n_loc), dtype=torch.float32, device=dev) if world > 1 else None
+
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
+    ws = torch.empty(lib.rtk_workspace_bytes(_lib.RTK_F32, B, n_rel, a, b, c), dtype=torch.uint8, device=dev)
+    qp = torch.empty(lib.rtk_packed_query_bytes(_lib.RTK_F32, B, c), dtype=torch.uint8, device=dev)
+    v = torch.empty((B, c), dtype=torch.float32, device=dev)
+
+    def step(i, ev=None):
+        h, r = pool[i % len(pool)]
+        _lib.check(lib.rtk_query_vectors_f32(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent,
+                                             r.data_ptr(), h.data_ptr(), B, v.data_ptr() if args.exact else None,
+                                             None if args.exact else qp.data_ptr(), ws.data_ptr(), ws.numel(), sp),
+                   "rtk_query_vectors_f32")
+        if ev:
+            ev[0].record(stream)
+        if args.exact:
+            _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
+                                         _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
+        else:
+            _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
+                                                _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_packed_f32")
+        if ev:
+            ev[1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, events[i])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+    # algorithmic bytes of ONE score-kernel launch: read the O shard once, write the scores once,
+    # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
+    alg_bytes = n_loc * c * 4 + B * n_loc * 4 + B * c * 4
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "1-vs-N triples scored/sec", "value": args.steps * B / dt, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "entities": n_ent, "relations": n_rel, "rank": list(trank),
+                   "batch": B, "scores_per_query": n_ent,
+                   "score_kernel": "exact_f32_mfma" if args.exact else "split_fp16_mfma",
+                   "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
+        "scores_per_s": args.steps * B * n_ent / dt,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "score_split_kernel" if not args.exact else "gemm_f32_kernel",
+                     "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(n_ent, n_rel, B, trank, pool_cpu)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+/*
+ * rtucker_hip.h -- C ABI of librtucker_hip.so: R-TuckER's 1-vs-all Tucker scoring
+ * path for AMD MI355X (gfx950 / CDNA4), hand-written HIP kernels.
+ *
+ * The reference (johanDDC/R-TuckER) has no native boundary: the path is the
+ * Python closure  score_fn = model(subject_idx, relation_idx);  P = score_fn(T)
+ * (src/model/asymmetric/R_TuckER.py:41-50, src/model/symmetric/R_TuckER.py:38-47).
+ * This header is the boundary a maintainer binds instead of the five torch ops
+ * inside that closure (INTEGRATION.md shows the ctypes stub).  Each entry point
+ * below cites the reference lines it replaces.
+ *
+ * Conventions
+ *  - plain C symbols, no C++/torch types; every pointer is a DEVICE pointer
+ *    (hipMalloc'd / torch tensor .data_ptr()) unless the name says "host";
+ *  - row-major, contiguous operands; sizes are element counts;
+ *  - core axis order is (relation a, subject b, object c)  [train.py:41,
+ *    asymmetric/R_TuckER.py:20-23];  factors R:(nR,a)  S:(nS,b)  O:(N,c);
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream); every call
+ *    only ENQUEUES work on it: no allocation, no synchronisation, no hidden
+ *    state besides a thread-local last-error string -> graph-capturable;
+ *  - scratch memory is caller-owned: query its size with rtk_workspace_bytes(),
+ *    pass it in; the same workspace must not be used by two in-flight calls;
+ *  - return value: 0 = RTK_OK, negative = rtk_status (nothing was enqueued).
+ *    Index values are range-checked ON DEVICE: an out-of-range id never reads
+ *    out of bounds (it is clamped) and raises bit 0 of the 32-bit word at the
+ *    start of the workspace, which rtk_read_error_flag() fetches (synchronising).
+ *    (Reference behaviour: torch raises IndexError / device assert.)
+ */
+#ifndef RTUCKER_HIP_H
+#define RTUCKER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtk_status {
+    RTK_OK = 0,
+    RTK_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, b != c ...        */
+    RTK_ERR_WORKSPACE = -2,    /* workspace missing or smaller than required        */
+    RTK_ERR_UNSUPPORTED = -3,  /* shape outside what the kernels implement          */
+    RTK_ERR_LAUNCH = -4        /* hipGetLastError() after a launch was not success  */
+} rtk_status;
+
+typedef enum rtk_dtype {
+    RTK_F32 = 0,   /* fp32 operands, fp32 scores (reference dtype, R_TuckER.py:23)   */
+    RTK_BF16 = 1   /* bf16 operands, fp32 accumulate, fp32 scores                    */
+} rtk_dtype;
+
+/* flags for the score stage */
+#define RTK_SCORE_SIGMOID 1u      /* apply sigmoid (R_TuckER.py:48); else raw logits  */
+#define RTK_SCORE_EXACT_F32 2u    /* fp32 operands: force the exact-fp32 MFMA kernel   */
+                                  /* instead of the split-fp16 (hi/lo) MFMA kernel     */
+
+int rtk_version(void);
+const char *rtk_last_error_string(void);
+
+/* Bytes of workspace the calls below need for these sizes (upper bound, 256-B aligned). */
+size_t rtk_workspace_bytes(int dtype, int64_t batch, int64_t n_rel, int a, int b, int c);
+
+/* Fetches and clears the device error word of a workspace (hipStreamSynchronize
+ * on `stream` first).  Bit 0: relation/subject index out of range. */
+int rtk_read_error_flag(void *workspace, void *stream, uint32_t *host_flag_out);
+
+/*
+ * Stage 1: query vectors  v[d,:] = S[h_d,:] . ( G x_0 R[r_d,:] )        (B x c)
+ * replaces asymmetric/R_TuckER.py:43-46 (two gathers, einsum "abc,da->dbc", bmm)
+ * and symmetric/R_TuckER.py:40-43 (pass E as S).  Requires b == c like the
+ * reference's .view(-1, b) -> RTK_ERR_BAD_ARG otherwise.
+ *   v_out    : fp32 (B x c), may be NULL
+ *   q_packed : "query planes" consumed by rtk_score_packed_*, may be NULL;
+ *              size rtk_packed_query_bytes(dtype, B, c)
+ * Internally: relation tables M_u = G x_0 R[u] for the distinct relations of the
+ * batch, then v_d = S[h_d] . M_{r_d}  (the reference's summation order).
+ */
+int rtk_query_vectors_f32(const float *core, int a, int b, int c,
+                          const float *R, int64_t n_rel,
+                          const float *S, int64_t n_sub,
+                          const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                          float *v_out, void *q_packed,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+size_t rtk_packed_query_bytes(int dtype, int64_t batch, int c);
+
+/*
+ * Stage 2: scores  out[d, j] = sigmoid( v[d,:] . O[j,:] )   for j < n_local
+ * replaces asymmetric/R_TuckER.py:47-48 ( @ T.factors[2].T ; sigmoid ) and
+ * symmetric/R_TuckER.py:44-45.  `O` is the (shard of the) entity matrix,
+ * (n_local x c) row-major; `out` has leading dimension ld_out >= n_local.
+ * rtk_score_f32        : exact fp32 MFMA (v_mfma_f32_32x32x2_f32), v in fp32.
+ * rtk_score_packed_f32 : split-fp16 MFMA path, v given as packed query planes.
+ */
+int rtk_score_f32(const float *v, int64_t batch, int c,
+                  const float *O, int64_t n_local,
+                  float *out, int64_t ld_out, unsigned flags, void *stream);
+
+int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c,
+                         const float *O, int64_t n_local,
+                         float *out, int64_t ld_out, unsigned flags, void *stream);
+
+/*
+ * Both stages: the whole closure body, asymmetric/R_TuckER.py:43-48.
+ * out (B x ld_out) receives sigmoid scores (or logits without RTK_SCORE_SIGMOID)
+ * against the n_local rows of O.  For the symmetric model pass S == O == E.
+ */
+int rtk_score_1vN_f32(const float *core, int a, int b, int c,
+                      const float *R, int64_t n_rel,
+                      const float *S, int64_t n_sub,
+                      const float *O, int64_t n_local,
+                      const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                      float *out, int64_t ld_out, unsigned flags,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * General fp32 MFMA GEMM used by the backward pass and as the exact fallback:
+ *   C[m,n] (+)= sum_k A(m,k) * B(n,k)
+ * A(m,k) = A[m*lda + k] if a_kmajor else A[k*lda + m]; likewise B(n,k).
+ * flags: RTK_SCORE_SIGMOID applies sigmoid to C.
+ */
+int rtk_gemm_f32(const float *A, int a_kmajor, int64_t lda,
+                 const float *B, int b_kmajor, int64_t ldb,
+                 float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                 unsigned flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTUCKER_HIP_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of ``librtucker_hip.so`` (C ABI: ``include/rtucker_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``r-tucker_amd/csrc/build.sh`` into ``r-tucker_amd/lib/``.  Loading is lazy and
+LOUD: if the shared object is missing or a symbol is absent, an exception is raised;
+there is no Python/CPU fallback for any entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librtucker_hip.so")
+
+RTK_OK = 0
+RTK_F32, RTK_BF16 = 0, 1
+RTK_SCORE_SIGMOID = 1
+RTK_SCORE_EXACT_F32 = 2
+
+_p, _i, _i64, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_uint
+
+# name -> (restype, argtypes); mirrors include/rtucker_hip.h one to one
+SIGNATURES = {
+    "rtk_version": (_i, []),
+    "rtk_last_error_string": (C.c_char_p, []),
+    "rtk_workspace_bytes": (_sz, [_i, _i64, _i64, _i, _i, _i]),
+    "rtk_packed_query_bytes": (_sz, [_i, _i64, _i]),
+    "rtk_read_error_flag": (_i, [_p, _p, C.POINTER(C.c_uint32)]),
+    "rtk_query_vectors_f32": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "rtk_score_f32": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _u, _p]),
+    "rtk_score_packed_f32": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _u, _p]),
+    "rtk_score_1vN_f32": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _u, _p, _sz, _p]),
+    "rtk_gemm_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _u, _p]),
+}
+
+_lib = None
+
+
+class RTuckerHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RTuckerHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or r-tucker_amd/csrc/build.sh).  There is no CPU fallback for the scoring path.")
+    import torch  # noqa: F401  -- torch's HIP runtime must be the one in the process before ours binds to it
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RTuckerHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != RTK_OK:
+        msg = load().rtk_last_error_string().decode(errors="replace")
+        # reference behaviour on bad shapes is a torch RuntimeError
+        raise RuntimeError(f"{what} failed with status {rc}: {msg}")

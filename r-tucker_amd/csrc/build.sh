@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build librtucker_hip.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p "$OUT" obj
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-function"
+pids=()
+for f in rtk_abi rtk_gemm_f32 rtk_query rtk_score_split; do
+  ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librtucker_hip.so" obj/*.o
+echo "built $OUT/librtucker_hip.so"

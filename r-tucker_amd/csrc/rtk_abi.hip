@@ -1,0 +1,122 @@
+// C-ABI entry points of librtucker_hip.so (declared in include/rtucker_hip.h):
+// argument validation, workspace carving, stage orchestration.  No allocation, no
+// synchronisation (except rtk_read_error_flag), no global state but the last-error text.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "rtk_common.h"
+#include "rtk_pack.h"
+
+static thread_local char g_err[512] = "";
+
+void rtk_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
+                               const float *S, int64_t n_sub, const int64_t *rel_idx,
+                               const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
+                               const RtkWorkspace &ws, hipStream_t st);
+int rtk_split_ksteps_supported(int c);
+
+static size_t packed_bytes(int dtype, int64_t batch, int c) {
+    const int ks = (c + 15) / 16;
+    return (size_t)rtk_cdiv(batch, 32) * (size_t)rtk_pack_tile_bytes(ks, dtype == RTK_F32 ? 2 : 1);
+}
+
+static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, int a, int b, int c) {
+    (void)a;
+    RtkWorkspace w;
+    unsigned char *p = (unsigned char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *q = p ? p + off : nullptr;
+        off += rtk_align_up(bytes, 256);
+        return q;
+    };
+    const int64_t n_u_max = n_rel > batch ? batch : n_rel;
+    w.flags = (uint32_t *)take(256);
+    w.slot_of_rel = (int32_t *)take((size_t)n_rel * 4);
+    w.rel_list = (int32_t *)take((size_t)n_u_max * 4);
+    w.tables = (float *)take((size_t)n_u_max * b * c * 4);
+    w.v = (float *)take((size_t)batch * c * 4);
+    w.q_packed = take(packed_bytes(dtype, batch, c));
+    w.total = off;
+    return w;
+}
+
+extern "C" int rtk_version(void) { return 100; }
+extern "C" const char *rtk_last_error_string(void) { return g_err; }
+
+extern "C" size_t rtk_workspace_bytes(int dtype, int64_t batch, int64_t n_rel, int a, int b, int c) {
+    if (batch <= 0 || n_rel <= 0 || a <= 0 || b <= 0 || c <= 0) return 0;
+    return carve(nullptr, dtype, batch, n_rel, a, b, c).total;
+}
+
+extern "C" size_t rtk_packed_query_bytes(int dtype, int64_t batch, int c) {
+    if (batch <= 0 || c <= 0) return 0;
+    return packed_bytes(dtype, batch, c);
+}
+
+extern "C" int rtk_read_error_flag(void *workspace, void *stream, uint32_t *host_flag_out) {
+    RTK_REQUIRE(workspace && host_flag_out, RTK_ERR_BAD_ARG, "rtk_read_error_flag: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(host_flag_out, workspace, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        rtk_set_error("rtk_read_error_flag: %s", hipGetErrorString(e));
+        return RTK_ERR_LAUNCH;
+    }
+    return RTK_OK;
+}
+
+static int check_common(const char *fn, const void *core, int a, int b, int c, const void *R, int64_t n_rel,
+                        const void *S, int64_t n_sub, const void *rel_idx, const void *sub_idx,
+                        int64_t batch, void *ws, size_t ws_bytes, int dtype) {
+    RTK_REQUIRE(core && R && S && rel_idx && sub_idx, RTK_ERR_BAD_ARG, "%s: null operand", fn);
+    RTK_REQUIRE(a > 0 && b > 0 && c > 0 && n_rel > 0 && n_sub > 0 && batch > 0, RTK_ERR_BAD_ARG,
+                "%s: sizes must be positive (a=%d b=%d c=%d n_rel=%lld n_sub=%lld batch=%lld)", fn, a, b, c,
+                (long long)n_rel, (long long)n_sub, (long long)batch);
+    // the reference's .view(-1, b) of a (B,1,c) tensor (asymmetric/R_TuckER.py:46) only works for b == c
+    RTK_REQUIRE(b == c, RTK_ERR_BAD_ARG, "%s: subject rank b=%d must equal object rank c=%d (the reference's view(-1, b) raises otherwise)", fn, b, c);
+    RTK_REQUIRE(n_rel < (1ll << 31) && batch < (1ll << 31), RTK_ERR_UNSUPPORTED, "%s: n_rel/batch exceed 2^31-1", fn);
+    const size_t need = rtk_workspace_bytes(dtype, batch, n_rel, a, b, c);
+    RTK_REQUIRE(ws && ws_bytes >= need, RTK_ERR_WORKSPACE, "%s: workspace of %zu bytes given, %zu needed", fn, ws_bytes, need);
+    RTK_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, RTK_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", fn);
+    return RTK_OK;
+}
+
+extern "C" int rtk_query_vectors_f32(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
+                                     const float *S, int64_t n_sub, const int64_t *rel_idx,
+                                     const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_common("rtk_query_vectors_f32", core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch,
+                          workspace, workspace_bytes, RTK_F32);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(v_out || q_packed, RTK_ERR_BAD_ARG, "rtk_query_vectors_f32: both outputs are NULL");
+    RtkWorkspace ws = carve(workspace, RTK_F32, batch, n_rel, a, b, c);
+    return rtk_query_vectors_f32_impl(core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch, v_out,
+                                      q_packed, ws, (hipStream_t)stream);
+}
+
+extern "C" int rtk_score_1vN_f32(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
+                                 const float *S, int64_t n_sub, const float *O, int64_t n_local,
+                                 const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *out,
+                                 int64_t ld_out, unsigned flags, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
+    int rc = check_common("rtk_score_1vN_f32", core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch,
+                          workspace, workspace_bytes, RTK_F32);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(O && out && n_local > 0 && ld_out >= n_local, RTK_ERR_BAD_ARG, "rtk_score_1vN_f32: bad O/out/n_local/ld_out");
+    RtkWorkspace ws = carve(workspace, RTK_F32, batch, n_rel, a, b, c);
+    const bool exact = (flags & RTK_SCORE_EXACT_F32) || !rtk_split_ksteps_supported(c);
+    rc = rtk_query_vectors_f32_impl(core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch,
+                                    exact ? ws.v : nullptr, exact ? nullptr : ws.q_packed, ws, (hipStream_t)stream);
+    if (rc != RTK_OK) return rc;
+    if (exact) return rtk_score_f32(ws.v, batch, c, O, n_local, out, ld_out, flags & RTK_SCORE_SIGMOID, stream);
+    return rtk_score_packed_f32(ws.q_packed, batch, c, O, n_local, out, ld_out, flags & RTK_SCORE_SIGMOID, stream);
+}

@@ -1,0 +1,233 @@
+// Exact-fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   C[m,n] = epi( sum_k A(m,k) * B(n,k) )
+//
+// Used for (a) the exact-fp32 score stage  Z = v . O^T  (+ fused sigmoid)
+// [reference: src/model/asymmetric/R_TuckER.py:47-48], (b) the relation tables
+// M_u = R[u,:] . G_(0) when the relation rank is large [R_TuckER.py:45 regrouped by
+// distinct relation], and (c) the backward GEMMs.  fp32-input MFMA is bit-for-bit
+// a k-ordered fmaf chain (MI355X_MICROARCH.md, Matrix cores), i.e. the same
+// numerics class as the reference's CPU sgemm.
+//
+// Tiling: 128x128 block tile, BK = 16, 4 waves as 2x2, each wave 64x64 = 2x2
+// MFMA tiles of 32x32 (64 accumulator VGPRs).  Both operands are staged in LDS
+// k-major-transposed ([k][m], m contiguous) so a fragment read is one
+// conflict-free ds_read_b32 per lane; the next k-tile's global loads are issued
+// before the MFMAs of the current one (register staging, write after barrier).
+#include "rtk_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // LDT: padded LDS row (floats)
+
+// 8 consecutive elements of one operand's tile for this thread.
+struct Stage8 {
+    float v[8];
+};
+
+// K-major operand: element (row, k) at base[row*ld + k].  Thread t owns row
+// (t & 127) of the tile and k in [kh, kh+8), kh = 8*(t >> 7).
+__device__ __forceinline__ void load_kmajor(Stage8 &s, const float *__restrict__ base, int64_t ld,
+                                            const int32_t *__restrict__ rows, int row0, int nrows,
+                                            int k0, int K, int t, bool vec_ok) {
+    const int r = row0 + (t & 127);
+    const int k = k0 + 8 * (t >> 7);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] = 0.f;
+    if (r >= nrows) return;
+    const int64_t rr = rows ? (int64_t)rows[r] : (int64_t)r;
+    const float *p = base + rr * ld + k;
+    if (vec_ok && k + 8 <= K) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(p);
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s.v[j] = x0[j];
+            s.v[4 + j] = x1[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k + j < K) s.v[j] = p[j];
+    }
+}
+__device__ __forceinline__ void store_kmajor(const Stage8 &s, float *__restrict__ tile, int t) {
+    const int m = t & 127, kh = 8 * (t >> 7);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[(kh + j) * LDT + m] = s.v[j];
+}
+
+// M-major operand: element (row, k) at base[k*ld + row].  Thread t owns k = t >> 4
+// and rows [m8, m8+8), m8 = 8*(t & 15).
+__device__ __forceinline__ void load_mmajor(Stage8 &s, const float *__restrict__ base, int64_t ld,
+                                            int row0, int nrows, int k0, int K, int t, bool vec_ok) {
+    const int k = k0 + (t >> 4);
+    const int r = row0 + 8 * (t & 15);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] = 0.f;
+    if (k >= K) return;
+    const float *p = base + (int64_t)k * ld + r;
+    if (vec_ok && r + 8 <= nrows) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(p);
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s.v[j] = x0[j];
+            s.v[4 + j] = x1[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (r + j < nrows) s.v[j] = p[j];
+    }
+}
+__device__ __forceinline__ void store_mmajor(const Stage8 &s, float *__restrict__ tile, int t) {
+    const int k = t >> 4, m8 = 8 * (t & 15);
+    f32x4 x0, x1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x0[j] = s.v[j];
+        x1[j] = s.v[4 + j];
+    }
+    *reinterpret_cast<f32x4 *>(&tile[k * LDT + m8]) = x0;
+    *reinterpret_cast<f32x4 *>(&tile[k * LDT + m8 + 4]) = x1;
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, bool SIGMOID>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(
+    const float *__restrict__ A, int64_t lda, const int32_t *__restrict__ a_rows, bool a_vec,
+    const float *__restrict__ B, int64_t ldb, bool b_vec,
+    float *__restrict__ C, int64_t ldc, int M, int N, int K,
+    const uint32_t *__restrict__ m_dev) {
+    __shared__ __attribute__((aligned(16))) float As[BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+
+    if (m_dev) M = min(M, (int)*m_dev);
+    const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN;
+    if (tile_m >= M) return;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    Stage8 sa, sb;
+    auto load = [&](int k0) {
+        if (A_KMAJOR) load_kmajor(sa, A, lda, a_rows, tile_m, M, k0, K, t, a_vec);
+        else load_mmajor(sa, A, lda, tile_m, M, k0, K, t, a_vec);
+        if (B_KMAJOR) load_kmajor(sb, B, ldb, nullptr, tile_n, N, k0, K, t, b_vec);
+        else load_mmajor(sb, B, ldb, tile_n, N, k0, K, t, b_vec);
+    };
+    auto stash = [&]() {
+        if (A_KMAJOR) store_kmajor(sa, As, t); else store_mmajor(sa, As, t);
+        if (B_KMAJOR) store_kmajor(sb, Bs, t); else store_mmajor(sb, Bs, t);
+    };
+
+    load(0);
+    stash();
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const bool more = k0 + BK < K;
+        if (more) load(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = 2 * ks + h;
+            const float a0 = As[kk * LDT + wm * 64 + r];
+            const float a1 = As[kk * LDT + wm * 64 + 32 + r];
+            const float b0 = Bs[kk * LDT + wn * 64 + r];
+            const float b1 = Bs[kk * LDT + wn * 64 + 32 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            stash();
+            __syncthreads();
+        }
+    }
+
+    // C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = tile_n + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = tile_m + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M && n < N) {
+                    float x = acc[i][j][e];
+                    if (SIGMOID) x = rtk_sigmoid(x);
+                    C[(int64_t)m * ldc + n] = x;
+                }
+            }
+        }
+}
+
+template <bool AK, bool BK_, bool SG>
+void launch(const float *A, int64_t lda, const int32_t *a_rows, bool a_vec, const float *B, int64_t ldb,
+            bool b_vec, float *C, int64_t ldc, int M, int N, int K, const uint32_t *m_dev,
+            hipStream_t st) {
+    dim3 grid((unsigned)rtk_cdiv(N, BN), (unsigned)rtk_cdiv(M, BM));
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, SG>), grid, dim3(256), 0, st, A, lda, a_rows, a_vec, B,
+                       ldb, b_vec, C, ldc, M, N, K, m_dev);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// Internal entry (also used by the query-vector stage for large relation rank):
+// optional row gather on A (K-major only) and a device-side row count.
+int rtk_gemm_f32_ex(const float *A, int a_kmajor, int64_t lda, const int32_t *a_rows,
+                    const float *B, int b_kmajor, int64_t ldb, float *C, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, unsigned flags, const uint32_t *m_dev,
+                    hipStream_t st) {
+    RTK_REQUIRE(A && B && C, RTK_ERR_BAD_ARG, "rtk_gemm_f32: null operand");
+    RTK_REQUIRE(M > 0 && N > 0 && K > 0, RTK_ERR_BAD_ARG, "rtk_gemm_f32: sizes must be positive (M=%lld N=%lld K=%lld)",
+                (long long)M, (long long)N, (long long)K);
+    RTK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), RTK_ERR_UNSUPPORTED,
+                "rtk_gemm_f32: dimension exceeds 2^31-1");
+    RTK_REQUIRE(rtk_cdiv(M, BM) <= 65535, RTK_ERR_UNSUPPORTED, "rtk_gemm_f32: M too large for grid.y");
+    RTK_REQUIRE(!(a_rows && !a_kmajor), RTK_ERR_BAD_ARG, "rtk_gemm_f32: row gather needs a K-major A");
+    RTK_REQUIRE(ldc >= N, RTK_ERR_BAD_ARG, "rtk_gemm_f32: ldc < N");
+    const bool a_vec = aligned16(A) && (lda % 4 == 0);
+    const bool b_vec = aligned16(B) && (ldb % 4 == 0);
+    const bool sg = (flags & RTK_SCORE_SIGMOID) != 0;
+    const int m = (int)M, n = (int)N, k = (int)K;
+#define RTK_GO(AK, BK_)                                                                              \
+    do {                                                                                             \
+        if (sg) launch<AK, BK_, true>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st); \
+        else launch<AK, BK_, false>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st);  \
+    } while (0)
+    if (a_kmajor && b_kmajor) RTK_GO(true, true);
+    else if (a_kmajor && !b_kmajor) RTK_GO(true, false);
+    else if (!a_kmajor && b_kmajor) RTK_GO(false, true);
+    else RTK_GO(false, false);
+#undef RTK_GO
+    return rtk_check_launch("rtk_gemm_f32");
+}
+
+extern "C" int rtk_gemm_f32(const float *A, int a_kmajor, int64_t lda, const float *B, int b_kmajor,
+                            int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                            unsigned flags, void *stream) {
+    return rtk_gemm_f32_ex(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, C, ldc, M, N, K, flags, nullptr,
+                           (hipStream_t)stream);
+}
+
+extern "C" int rtk_score_f32(const float *v, int64_t batch, int c, const float *O, int64_t n_local,
+                             float *out, int64_t ld_out, unsigned flags, void *stream) {
+    RTK_REQUIRE(c > 0, RTK_ERR_BAD_ARG, "rtk_score_f32: c must be positive");
+    return rtk_gemm_f32_ex(v, 1, c, nullptr, O, 1, c, out, ld_out, batch, n_local, c,
+                           flags & RTK_SCORE_SIGMOID, nullptr, (hipStream_t)stream);
+}

@@ -1,0 +1,248 @@
+// Stage 1 of the scoring path: query vectors
+//     v[d,:] = S[h_d,:] . ( G x_0 R[r_d,:] )            (reference: asymmetric/R_TuckER.py:43-46)
+// computed in the reference's summation order (relation mode first, then subject
+// mode), but regrouped by DISTINCT relation so the (B,b,c) intermediate of the
+// reference's einsum never exists:
+//     plan     : distinct relations of the batch -> slots           (only if n_rel > B)
+//     tables   : M_u[b,c] = sum_a R[u,a] * G[a,b,c]   for each slot u   (n_u*a*b*c FMAs)
+//     contract : v_d[c]   = sum_b S[h_d,b] * M_{slot(r_d)}[b,c]         (B*b*c FMAs)
+// The contract kernel owns whole rows of v, so it also emits the "packed query
+// planes" the split-fp16 score kernel consumes (per-row power-of-two scaling and
+// hi/lo fp16 split in MFMA-fragment order; layout in rtk_pack.h).
+#include "rtk_common.h"
+#include "rtk_pack.h"
+
+namespace {
+
+// ---------------------------------------------------------------- plan ------
+// One workgroup.  slot_of_rel[r] = slot or -1; rel_list[slot] = r; flags[1] = n_u.
+// Slot order is arbitrary (atomic ticket); nothing downstream depends on it.
+__global__ __launch_bounds__(1024) void plan_kernel(const int64_t *__restrict__ rel_idx, int B, int n_rel,
+                                                    int32_t *__restrict__ slot_of_rel,
+                                                    int32_t *__restrict__ rel_list,
+                                                    uint32_t *__restrict__ flags) {
+    __shared__ unsigned count;
+    const int t = threadIdx.x;
+    if (t == 0) count = 0;
+    for (int r = t; r < n_rel; r += blockDim.x) slot_of_rel[r] = -1;
+    __syncthreads();
+    bool bad = false;
+    for (int d = t; d < B; d += blockDim.x) {
+        const int64_t r = rel_idx[d];
+        if (r < 0 || r >= n_rel) bad = true;
+        else slot_of_rel[r] = -2;  // benign race: every writer stores the same value
+    }
+    if (bad) atomicOr(&flags[0], 1u);
+    __syncthreads();
+    for (int r = t; r < n_rel; r += blockDim.x) {
+        if (slot_of_rel[r] == -2) {
+            const unsigned s = atomicAdd(&count, 1u);
+            slot_of_rel[r] = (int32_t)s;
+            rel_list[s] = r;
+        }
+    }
+    __syncthreads();
+    if (t == 0) flags[1] = count;
+}
+
+// -------------------------------------------------------------- tables ------
+// M[u, n] = sum_a R[rel(u), a] * G[a, n],  n in [0, b*c).  Streaming VALU kernel for
+// small relation rank (a <= 32: WN18RR has a = 10): each thread owns one float4 of
+// n for UT relations, so every G element is loaded once per UT relations.
+constexpr int UT = 8;
+template <bool VEC>
+__global__ __launch_bounds__(256) void tables_kernel(const float *__restrict__ G, int a, int64_t bc,
+                                                     const float *__restrict__ R,
+                                                     const int32_t *__restrict__ rel_list, int n_u_max,
+                                                     const uint32_t *__restrict__ n_u_dev,
+                                                     float *__restrict__ M) {
+    __shared__ float Rs[UT * 64];  // UT relations x a (a <= 64 here)
+    const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
+    const int u0 = blockIdx.y * UT;
+    if (u0 >= n_u) return;
+    const int t = threadIdx.x;
+    for (int i = t; i < UT * a; i += 256) {
+        const int u = u0 + i / a, ai = i % a;
+        float x = 0.f;
+        if (u < n_u) {
+            const int rel = rel_list ? rel_list[u] : u;
+            x = R[(int64_t)rel * a + ai];
+        }
+        Rs[(i / a) * 64 + ai] = x;
+    }
+    __syncthreads();
+    constexpr int W = VEC ? 4 : 1;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + t) * W;
+    if (n >= bc) return;
+    float acc[UT][W];
+#pragma unroll
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[u][j] = 0.f;
+    for (int ai = 0; ai < a; ++ai) {
+        float g[W];
+        if (VEC) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(G + (int64_t)ai * bc + n);
+#pragma unroll
+            for (int j = 0; j < W; ++j) g[j] = x[j];
+        } else {
+            g[0] = G[(int64_t)ai * bc + n];
+        }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const float rv = Rs[u * 64 + ai];
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[u][j] = fmaf(rv, g[j], acc[u][j]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        if (u0 + u >= n_u) break;
+        float *dst = M + (int64_t)(u0 + u) * bc + n;
+        if (VEC) {
+            f32x4 x;
+#pragma unroll
+            for (int j = 0; j < W; ++j) x[j] = acc[u][j];
+            *reinterpret_cast<f32x4 *>(dst) = x;
+        } else {
+            dst[0] = acc[u][0];
+        }
+    }
+}
+
+// ------------------------------------------------------------ contract ------
+// One workgroup per query d:  v_d[c] = sum_b S[h_d, b] * M_slot[b, c].
+// 256 threads = G groups x (c/W) column slots; group g takes b = g, g+G, ...;
+// partial sums meet in LDS.  The finished row is written as fp32 and/or packed.
+template <bool VEC>
+__global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__ M, int b, int c,
+                                                       const float *__restrict__ S, int64_t n_sub,
+                                                       const int64_t *__restrict__ rel_idx,
+                                                       const int64_t *__restrict__ sub_idx, int n_rel,
+                                                       const int32_t *__restrict__ slot_of_rel,
+                                                       float *__restrict__ v_out,
+                                                       unsigned char *__restrict__ q_packed, int ksteps,
+                                                       uint32_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_row = smem;                      // b floats
+    float *part = smem + ((b + 3) & ~3);      // G * cpad floats, later the finished row
+    __shared__ float red[4];
+    constexpr int W = VEC ? 4 : 1;
+    const int d = blockIdx.x, t = threadIdx.x;
+    const int cols = (c + W - 1) / W;         // column slots
+    const int cpad = cols * W;
+    const int ngroups = max(1, 256 / cols);   // groups of b
+    const int npass = (cols + 255) / 256;     // > 1 only when cols > 256
+
+    int64_t h = sub_idx[d], r = rel_idx[d];
+    bool bad = false;
+    if (h < 0 || h >= n_sub) { bad = true; h = 0; }
+    if (r < 0 || r >= n_rel) { bad = true; r = 0; }
+    if (bad && t == 0) atomicOr(&flags[0], 1u);
+    const int slot = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+    const float *Mq = M + (int64_t)slot * b * c;
+
+    for (int i = t; i < b; i += 256) s_row[i] = S[h * b + i];
+    __syncthreads();
+
+    for (int pass = 0; pass < npass; ++pass) {
+        const int g = (npass == 1) ? t / cols : 0;
+        const int col = (npass == 1) ? t % cols : pass * 256 + t;
+        const bool active = (npass == 1) ? (g < ngroups) : (col < cols);
+        float acc[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] = 0.f;
+        if (active) {
+            const int gstep = (npass == 1) ? ngroups : 1;
+#pragma unroll 4
+            for (int bi = g; bi < b; bi += gstep) {
+                const float sv = s_row[bi];
+                if (VEC) {
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(Mq + (int64_t)bi * c + col * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(sv, x[j], acc[j]);
+                } else {
+                    acc[0] = fmaf(sv, Mq[(int64_t)bi * c + col], acc[0]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) part[g * cpad + col * W + j] = acc[j];
+        }
+    }
+    __syncthreads();
+    // reduce the groups; thread k owns element k of the row (k < c), looped if c > 256
+    const int ng = (npass == 1) ? ngroups : 1;
+    float mx = 0.f;
+    for (int k = t; k < c; k += 256) {
+        float x = 0.f;
+        for (int g = 0; g < ng; ++g) x += part[g * cpad + k];
+        part[k] = x;  // slot g = 0 of column k: only this thread touches column k from here on
+        mx = fmaxf(mx, fabsf(x));
+        if (v_out) v_out[(int64_t)d * c + k] = x;
+    }
+    if (!q_packed) return;
+    // row maximum -> power-of-two scale
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int sh = rtk_pack_shift(mx);
+    const float up = ldexpf(1.0f, sh);
+    unsigned char *tile = q_packed + (int64_t)(d >> 5) * rtk_pack_tile_bytes(ksteps, 2);
+    const int row = d & 31;
+    if (t == 0) reinterpret_cast<float *>(tile)[row] = ldexpf(1.0f, -sh);
+    _Float16 *planes = reinterpret_cast<_Float16 *>(tile + RTK_PACK_HDR);
+    for (int k = t; k < ksteps * 16; k += 256) {
+        const float x = (k < c) ? part[k] * up : 0.f;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        const int off = rtk_pack_offset(ksteps, k, row);
+        planes[off] = hi;
+        planes[off + ksteps * 512] = lo;  // plane 1 follows plane 0 (ksteps*2*32*8 halves)
+    }
+}
+
+}  // namespace
+
+int rtk_gemm_f32_ex(const float *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const float *B,
+                    int b_kmajor, int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                    unsigned flags, const uint32_t *m_dev, hipStream_t st);
+
+// Enqueue stage 1.  `ws` already carved (rtk_abi.hip).
+int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
+                               const float *S, int64_t n_sub, const int64_t *rel_idx,
+                               const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
+                               const RtkWorkspace &ws, hipStream_t st) {
+    const int64_t bc = (int64_t)b * c;
+    const bool planned = n_rel > batch;  // otherwise: one table per relation id, slot == id
+    const int n_u_max = (int)(planned ? batch : n_rel);
+    hipMemsetAsync(ws.flags, 0, 16, st);
+    if (planned) {
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, rel_idx, (int)batch, (int)n_rel,
+                           ws.slot_of_rel, ws.rel_list, ws.flags);
+    }
+    const int32_t *rel_list = planned ? ws.rel_list : nullptr;
+    const uint32_t *n_u_dev = planned ? ws.flags + 1 : nullptr;
+    if (a <= 32) {
+        const bool vec = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(core) & 15) == 0);
+        const int W = vec ? 4 : 1;
+        dim3 grid((unsigned)rtk_cdiv(bc, 256 * W), (unsigned)rtk_cdiv(n_u_max, UT));
+        if (vec) hipLaunchKernelGGL(tables_kernel<true>, grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
+        else hipLaunchKernelGGL(tables_kernel<false>, grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
+    } else {
+        // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM
+        int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, ws.tables, bc, n_u_max, bc, a, 0, n_u_dev, st);
+        if (rc != RTK_OK) return rc;
+    }
+    const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws.tables) & 15) == 0);
+    const int W = vec ? 4 : 1;
+    const int cols = (c + W - 1) / W;
+    const int ngroups = cols >= 256 ? 1 : 256 / cols;
+    const size_t smem = (size_t)(((b + 3) & ~3) + (size_t)ngroups * cols * W) * sizeof(float);
+    RTK_REQUIRE(smem <= 64 * 1024, RTK_ERR_UNSUPPORTED, "rtk_query_vectors: rank too large for the contract kernel (b=%d c=%d)", b, c);
+    const int ksteps = (c + 15) / 16;
+    if (vec) hipLaunchKernelGGL(contract_kernel<true>, dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
+    else hipLaunchKernelGGL(contract_kernel<false>, dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
+    return rtk_check_launch("rtk_query_vectors_f32");
+}

@@ -1,0 +1,189 @@
+"""Host side of the scoring path: tensor checks, workspace, stream, autograd.
+
+``score_1vN`` is what ``score_fn(T)`` of both model flavours calls; it replaces the
+five torch ops of ``src/model/asymmetric/R_TuckER.py:43-48`` with one call into the
+C ABI (``rtk_score_1vN_f32``).  Forward runs entirely in the hand-written HIP
+kernels.  Backward (needed because the optimizer differentiates ``loss_fn(T)``,
+``train.py:79-82``) currently composes device-side torch ops around the saved
+query vectors; it never leaves the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _require_gpu(name, t):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: r_tucker_amd scores on MI355X only (no CPU path; "
+            "use the reference implementation or oracle/ for CPU runs)")
+
+
+def _f32c(name, t):
+    _require_gpu(name, t)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 for the fp32 path, got {t.dtype}")
+    return t.contiguous()
+
+
+def _idx(name, t, device):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    if t.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8, torch.int8):
+        raise IndexError(f"{name} must be an integer tensor, got {t.dtype}")  # torch: "tensors used as indices must be long..."
+    return t.to(device=device, dtype=torch.int64).contiguous().view(-1)
+
+
+def _workspace(device, stream_ptr, nbytes):
+    key = (device.index, stream_ptr)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v):
+    lib = _lib.load()
+    core, R, S, O = _f32c("core", core), _f32c("R", R), _f32c("S", S), _f32c("O", O)
+    dev = core.device
+    for n, t in (("R", R), ("S", S), ("O", O)):
+        if t.device != dev:
+            raise RuntimeError(f"{n} is on {t.device}, core on {dev}")
+    if core.dim() != 3 or R.dim() != 2 or S.dim() != 2 or O.dim() != 2:
+        raise RuntimeError("expected core (a,b,c), R (nR,a), S (N,b), O (N,c)")
+    a, b, c = core.shape
+    if R.shape[1] != a or S.shape[1] != b or O.shape[1] != c:
+        raise RuntimeError(f"factor widths {R.shape[1]},{S.shape[1]},{O.shape[1]} do not match core {tuple(core.shape)}")
+    h = _idx("subject_idx", subject_idx, dev)
+    r = _idx("relation_idx", relation_idx, dev)
+    if h.numel() != r.numel():
+        raise RuntimeError(f"subject_idx has {h.numel()} entries, relation_idx {r.numel()}")
+    B, N = h.numel(), O.shape[0]
+    if b != c:
+        # asymmetric/R_TuckER.py:46: .view(-1, b) of a (B,1,c) tensor
+        raise RuntimeError(f"shape '[-1, {b}]' is invalid for input of size {B * c}")
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if B == 0:
+        return out, None
+    with torch.cuda.device(dev):
+        sp = _stream_ptr(dev)
+        need = lib.rtk_workspace_bytes(_lib.RTK_F32, B, R.shape[0], a, b, c)
+        ws = _workspace(dev, sp, need)
+        flags = (_lib.RTK_SCORE_SIGMOID if sigmoid else 0) | (_lib.RTK_SCORE_EXACT_F32 if exact else 0)
+        v = None
+        if want_v:
+            # two-call form so the fp32 query vectors are kept for backward
+            v = torch.empty((B, c), dtype=torch.float32, device=dev)
+            use_packed = not exact and c <= 512
+            qp = None
+            if use_packed:
+                qp = torch.empty(lib.rtk_packed_query_bytes(_lib.RTK_F32, B, c), dtype=torch.uint8, device=dev)
+            _lib.check(lib.rtk_query_vectors_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0],
+                                                 S.data_ptr(), S.shape[0], r.data_ptr(), h.data_ptr(), B,
+                                                 v.data_ptr(), qp.data_ptr() if use_packed else None,
+                                                 ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_f32")
+            if use_packed:
+                _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), N,
+                                                    flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_packed_f32")
+            else:
+                _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), N,
+                                             flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
+        else:
+            _lib.check(lib.rtk_score_1vN_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0],
+                                             S.data_ptr(), S.shape[0], O.data_ptr(), N,
+                                             r.data_ptr(), h.data_ptr(), B, out.data_ptr(), N, flags,
+                                             ws.data_ptr(), ws.numel(), sp), "rtk_score_1vN_f32")
+    return out, v
+
+
+class _Score1vN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, core, R, S, O, subject_idx, relation_idx, sigmoid, exact):
+        out, v = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=True)
+        dev = core.device
+        ctx.save_for_backward(core, R, S, O, _idx("s", subject_idx, dev), _idx("r", relation_idx, dev), v, out)
+        ctx.sigmoid = sigmoid
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        core, R, S, O, h, r, v, out = ctx.saved_tensors
+        dZ = grad_out * out * (1 - out) if ctx.sigmoid else grad_out
+        dZ = dZ.contiguous()
+        gO = dZ.t() @ v if ctx.needs_input_grad[3] else None                 # (N, c)
+        dv = dZ @ O                                                          # (B, c)
+        Rb, Sb = R[r], S[h]
+        W = torch.einsum("abc,dc->dab", core, dv)                            # (B, a, b)
+        gcore = torch.einsum("da,db,dc->abc", Rb, Sb, dv) if ctx.needs_input_grad[0] else None
+        gR = gS = None
+        if ctx.needs_input_grad[1]:
+            gR = torch.zeros_like(R).index_add_(0, r, torch.einsum("dab,db->da", W, Sb))
+        if ctx.needs_input_grad[2]:
+            gS = torch.zeros_like(S).index_add_(0, h, torch.einsum("dab,da->db", W, Rb))
+        # symmetric model: S and O are the same tensor passed twice; autograd sums gS + gO
+        return gcore, gR, gS, gO, None, None, None, None
+
+
+def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=False):
+    """``sigmoid((G x_0 R[r] x_1 S[h]) . O^T)`` for a batch of (h, r) queries -> ``(B, N)``.
+
+    Same operands and result as the body of the reference's ``score_fn``
+    (asymmetric/R_TuckER.py:43-48; symmetric: pass ``S is O``).  ``exact=True``
+    selects the exact-fp32 MFMA score kernel instead of the split-fp16 one.
+    """
+    needs_grad = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (core, R, S, O))
+    if needs_grad:
+        return _Score1vN.apply(core, R, S, O, subject_idx, relation_idx, sigmoid, exact)
+    out, _ = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False)
+    return out
+
+
+def query_vectors(core, R, S, subject_idx, relation_idx):
+    """Stage 1 only: ``v[d] = S[h_d] . (G x_0 R[r_d])`` -> ``(B, c)`` fp32 (R_TuckER.py:43-46)."""
+    lib = _lib.load()
+    core, R, S = _f32c("core", core), _f32c("R", R), _f32c("S", S)
+    dev = core.device
+    a, b, c = core.shape
+    h, r = _idx("subject_idx", subject_idx, dev), _idx("relation_idx", relation_idx, dev)
+    B = h.numel()
+    v = torch.empty((B, c), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        sp = _stream_ptr(dev)
+        ws = _workspace(dev, sp, lib.rtk_workspace_bytes(_lib.RTK_F32, B, R.shape[0], a, b, c))
+        _lib.check(lib.rtk_query_vectors_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0], S.data_ptr(),
+                                             S.shape[0], r.data_ptr(), h.data_ptr(), B, v.data_ptr(), None,
+                                             ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_f32")
+    return v
+
+
+def check_device_errors(device=None):
+    """Synchronise and raise ``IndexError`` if a kernel saw an out-of-range subject /
+    relation id since the last check (the kernels clamp such ids instead of faulting;
+    the reference raises IndexError on CPU / asserts on device)."""
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    bad = False
+    for (di, sp), ws in _workspaces.items():
+        if di != dev.index:
+            continue
+        flag = C.c_uint32(0)
+        _lib.check(lib.rtk_read_error_flag(ws.data_ptr(), sp, C.byref(flag)), "rtk_read_error_flag")
+        if flag.value & 1:
+            bad = True
+            ws[:4].zero_()
+    if bad:
+        raise IndexError("index out of range in self (subject_idx / relation_idx)")
