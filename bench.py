@@ -103,7 +103,7 @@ def main():
 
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
-    ws = torch.empty(lib.rtk_workspace_bytes(_lib.RTK_F32, B, n_rel, a, b, c), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.rtk_workspace_bytes(_lib.RTK_F32, B, n_rel, a, b, c), dtype=torch.uint8, device=dev)
     qp = torch.empty(lib.rtk_packed_query_bytes(_lib.RTK_F32, B, c), dtype=torch.uint8, device=dev)
     v = torch.empty((B, c), dtype=torch.float32, device=dev)
 

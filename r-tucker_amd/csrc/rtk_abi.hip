@@ -118,5 +118,6 @@ extern "C" int rtk_score_1vN_f32(const float *core, int a, int b, int c, const f
                                     exact ? ws.v : nullptr, exact ? nullptr : ws.q_packed, ws, (hipStream_t)stream);
     if (rc != RTK_OK) return rc;
     if (exact) return rtk_score_f32(ws.v, batch, c, O, n_local, out, ld_out, flags & RTK_SCORE_SIGMOID, stream);
-    return rtk_score_packed_f32(ws.q_packed, batch, c, O, n_local, out, ld_out, flags & RTK_SCORE_SIGMOID, stream);
+    return rtk_score_packed_f32(ws.q_packed, batch, c, O, n_local, out, ld_out,
+                                flags & (RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST), stream);
 }

@@ -217,7 +217,8 @@ int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const flo
     const int64_t bc = (int64_t)b * c;
     const bool planned = n_rel > batch;  // otherwise: one table per relation id, slot == id
     const int n_u_max = (int)(planned ? batch : n_rel);
-    hipMemsetAsync(ws.flags, 0, 16, st);
+    // the error word (flags[0]) is sticky and owned by the caller: zeroed at workspace creation
+    // and by rtk_read_error_flag, not per call (a memset node costs ~4 us per batch)
     if (planned) {
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, rel_idx, (int)batch, (int)n_rel,
                            ws.slot_of_rel, ws.rel_list, ws.flags);

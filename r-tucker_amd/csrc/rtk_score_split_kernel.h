@@ -1,0 +1,223 @@
+// The split-fp16 score kernel (included by rtk_score_split.hip and by the ablation
+// build tools/ablate/rtk_score_ablate.hip).  Design notes: rtk_score_split.hip.
+#pragma once
+#include "rtk_common.h"
+#include "rtk_pack.h"
+
+namespace rtk_split {
+
+// SIGMOID: 0 = raw logits, 1 = ocml expf + IEEE divide (torch-CPU formula, ~25 VALU),
+//          2 = v_exp_f32 / v_rcp_f32 + one Newton step (7 VALU, <= ~2 ulp for z >= 0)
+__device__ __forceinline__ float logistic_fast(float z) {
+    const float t = fminf(z * -1.4426950408889634f, 126.0f);  // exp2 argument; clamp keeps 1+e finite
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float d = 1.0f + e;
+    const float p = __builtin_amdgcn_rcpf(d);
+    const float rr = fmaf(-d, p, 1.0f);
+    return fmaf(p, rr, p);
+}
+
+template <int KS, int SIGMOID, int MINW, unsigned ABL = 0>
+__global__ __launch_bounds__(256, MINW) void score_split_kernel(
+    const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
+    float *__restrict__ out, int64_t ld_out, bool o_vec) {
+    // ABL != 0 only in tools/ablate (compile-time ablations): bit0 skip staging, bit1 skip MFMA,
+    // bit2 skip stores, bit3 skip the query sweep (prologue only), bit4 skip the O conversion,
+    // bit5 skip the barriers
+    auto off = [](unsigned bit) { return (ABL & bit) != 0; };
+    constexpr int TILE_BYTES = RTK_PACK_HDR + 2 * KS * 1024;
+    constexpr int CHUNKS = TILE_BYTES / 16;
+    constexpr int NLD = (CHUNKS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * TILE_BYTES
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_mt = (B + 31) / 32;
+    // linearised (entity tile, query tile) space split evenly over the grid: perfect
+    // balance, at most one extra O-tile conversion per block
+    const int64_t U = (int64_t)((N + 127) / 128) * n_mt;
+    int64_t lin = U * blockIdx.x / gridDim.x;
+    const int64_t lin_end = U * (blockIdx.x + 1) / gridDim.x;
+
+    while (lin < lin_end) {
+        const int ntile = (int)(lin / n_mt), mt0 = (int)(lin % n_mt);
+        const int cnt = (int)min((int64_t)(n_mt - mt0), lin_end - lin);
+        lin += cnt;
+        const int j = ntile * 128 + wave * 32 + r;  // entity (row of O, column of out)
+
+        // ---- this lane's slice of O row j -> scaled hi/lo fp16 B fragments ----
+        // lane (r, h) holds k = 16*ks + 8*h + q, q < 8  (B-operand map of 32x32x16).  One
+        // round of loads straight into registers (all 2*KS float4 in flight together: a single
+        // exposed memory latency, no LDS phase, no barrier), then row max -> power-of-two
+        // scale -> hi/lo split in place.  Every byte of O is requested exactly once.
+        const float *orow = O + (int64_t)min(j, N - 1) * c;
+        float raw[KS][8];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 16 * ks + 8 * h;
+            if (off(16)) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) raw[ks][q] = (float)(lane + q + ks);
+            } else if (o_vec) {  // c % 4 == 0: each float4 is wholly inside or wholly outside the row
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                if (k + 4 <= c) a = *reinterpret_cast<const f32x4 *>(orow + k);
+                if (k + 8 <= c) b = *reinterpret_cast<const f32x4 *>(orow + k + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    raw[ks][q] = a[q];
+                    raw[ks][4 + q] = b[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) raw[ks][q] = (k + q < c) ? orow[k + q] : 0.f;
+            }
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mx = fmaxf(mx, fabsf(raw[ks][q]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const int sh = rtk_pack_shift(mx);
+        const float up = ldexpf(1.0f, sh);
+        const float us_o = ldexpf(1.0f, -sh);
+        f16x8 Bh[KS], Bl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float y = raw[ks][q] * up;
+                const _Float16 hi = (_Float16)y;
+                Bh[ks][q] = hi;
+                Bl[ks][q] = (_Float16)(y - (float)hi);
+            }
+        }
+        if (off(8)) {  // prologue only: keep the fragments alive
+            float keep = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) keep += (float)Bh[ks][0] + (float)Bl[ks][7];
+            if (keep == 12345.678f) out[0] = keep;
+            continue;
+        }
+
+        // ---- sweep `cnt` query tiles, software pipelined ----
+        //   iteration i:  global loads of tile i+1 in flight  |  MFMAs of tile i  |
+        //                 logistic + stores of tile i-1       |  ds_write tile i+1 ; barrier
+        u32x4 stg[NLD];
+        auto stage_load = [&](int mt) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(q_packed + (int64_t)mt * TILE_BYTES);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int ch = i * 256 + t;
+                if (!off(1) && (i + 1 < NLD || ch < CHUNKS)) stg[i] = src[ch];
+            }
+        };
+        auto stage_store = [&](int buf) {
+            u32x4 *dst = reinterpret_cast<u32x4 *>(lds + buf * TILE_BYTES);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int ch = i * 256 + t;
+                if (!off(1) && (i + 1 < NLD || ch < CHUNKS)) dst[ch] = stg[i];
+            }
+        };
+        // Stores go through a buffer descriptor rebased per query tile: rows past B fall
+        // outside num_records and lanes past N carry a poisoned offset, so the hardware
+        // drops them -- the epilogue is branch-free and the scheduler can place it in the
+        // shadow of the next tile's MFMA chain.
+        const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
+        __amdgpu_buffer_rsrc_t ers;  // descriptor of the tile whose epilogue is running
+        auto epilogue_begin = [&](int mt, bool live) {
+            const int rows = live ? min(32, B - mt * 32) : 0;
+            ers = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)max(mt, 0) * 32 * ld_out, 0,
+                                                    (unsigned)(rows * ld_out * 4), 0x00020000);
+        };
+        // The epilogue of one tile is cut into 32 pieces (16 accumulator elements x
+        // {exponential half, reciprocal half + store}) that the k-loop drops into the gaps
+        // between its dependent MFMAs: a 32x32x16 MFMA occupies the matrix pipe for 32 cycles
+        // but the wave's issue port for 8, so ~6 independent VALU instructions issue for free.
+        float ep_d = 1.f, ep_p = 1.f;
+        auto piece = [&](const f32x16 &z, int pc) {
+            const int e = pc >> 1;
+            if ((pc & 1) == 0) {
+                if (SIGMOID == 2) {
+                    const float tt = fminf(z[e] * -1.4426950408889634f, 126.0f);
+                    ep_d = 1.0f + __builtin_amdgcn_exp2f(tt);
+                    ep_p = __builtin_amdgcn_rcpf(ep_d);
+                } else if (SIGMOID == 1) {
+                    ep_d = 1.0f + expf(-z[e]);
+                } else {
+                    ep_p = z[e];
+                }
+            } else {
+                float pv = ep_p;
+                if (SIGMOID == 2) pv = fmaf(ep_p, fmaf(-ep_d, ep_p, 1.0f), ep_p);
+                if (SIGMOID == 1) pv = 1.0f / ep_d;
+                const int row = (e & 3) + 8 * (e >> 2);  // + 4*h inside voff
+                if (off(4)) {
+                    if (pv == 12345.678f) out[0] = pv;
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers,
+                                                          voff + (unsigned)(row * ld_out * 4), 0, 0);
+                }
+            }
+        };
+
+        stage_load(mt0);
+        stage_store(0);
+        __syncthreads();
+        f32x16 prev;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) prev[e] = 0.f;
+        for (int i = 0; i < cnt; ++i) {
+            const int cur = i & 1;
+            if (i + 1 < cnt) stage_load(mt0 + i + 1);
+            const unsigned char *tile = lds + cur * TILE_BYTES;
+            const f16x8 *lh = reinterpret_cast<const f16x8 *>(tile + RTK_PACK_HDR);
+            const f16x8 *ll = lh + KS * 64;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            epilogue_begin(mt0 + i - 1, i > 0);
+            constexpr int GAPS = 3 * KS;  // one gap after every MFMA
+            f16x8 ah = lh[lane], al = ll[lane];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f16x8 nh = ah, nl = al;
+                if (ks + 1 < KS) {  // A fragments one k-step ahead
+                    nh = lh[(ks + 1) * 64 + lane];
+                    nl = ll[(ks + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int g = 3 * ks + m;
+                    if (off(2)) {
+                        acc[g & 15] += (float)ah[m] * (float)Bh[ks][m] + (float)al[m] * (float)Bl[ks][m];
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m == 2 ? al : ah, m == 1 ? Bl[ks] : Bh[ks], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int pc = g * 32 / GAPS; pc < (g + 1) * 32 / GAPS; ++pc) piece(prev, pc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ah = nh;
+                al = nl;
+            }
+            // unscale while this tile's row factors are still in LDS:
+            // C/D map  column = lane & 31 (entity), row = (e & 3) + 8*(e >> 2) + 4*h
+            const float *lscale = reinterpret_cast<const float *>(tile);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sv = *reinterpret_cast<const f32x4 *>(lscale + 8 * g + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) prev[4 * g + q] = acc[4 * g + q] * sv[q] * us_o;
+            }
+            stage_store(cur ^ 1);  // unconditional: a stale tile in the spare buffer is never read
+            if (!off(32)) __syncthreads();
+        }
+        epilogue_begin(mt0 + cnt - 1, true);
+#pragma unroll
+        for (int pc = 0; pc < 32; ++pc) piece(prev, pc);
+    }
+}
+
+}  // namespace rtk_split

@@ -47,6 +47,7 @@ def _workspace(device, stream_ptr, nbytes):
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        ws[:256].zero_()   # header: sticky error word, owned by the caller (include/rtucker_hip.h)
         _workspaces[key] = ws
     return ws
 

@@ -1,0 +1,26 @@
+// Ablation build of the split-fp16 score kernel (NOT part of librtucker_hip.so): the same
+// kernel source instantiated with compile-time ablation masks, to see where the time goes.
+// Build: tools/ablate/build.sh -> tools/ablate/librtk_ablate.so
+#include "rtk_score_split_kernel.h"
+
+void rtk_set_error(const char *, ...) {}
+
+template <int SG, unsigned ABL>
+static void go(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld, unsigned grid,
+               hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)(RTK_PACK_HDR + 2 * 13 * 1024);
+    hipLaunchKernelGGL((rtk_split::score_split_kernel<13, SG, 2, ABL>), dim3(grid), dim3(256), smem, st,
+                       (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld, c % 4 == 0);
+}
+
+extern "C" int rtk_ablate_score_packed_f32(const void *qp, int64_t B, int c, const float *O, int64_t N,
+                                           float *out, int64_t ld, int sigmoid, int grid, unsigned abl,
+                                           void *stream) {
+    if ((c + 15) / 16 != 13) return -3;
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(SG, A) if (sigmoid == SG && abl == A) { go<SG, A>(qp, B, c, O, N, out, ld, grid, st); return (int)hipGetLastError(); }
+    CASE(2, 0) CASE(1, 0) CASE(0, 0)
+    CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(2, 8) CASE(2, 16) CASE(2, 20) CASE(2, 32) CASE(2, 36) CASE(2, 21) CASE(2, 53)
+    CASE(0, 21) CASE(0, 22) CASE(2, 19) CASE(0, 53) CASE(2, 5) CASE(2, 37)
+    return -5;
+}
