@@ -41,24 +41,36 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(n_ent, n_rel, B, rank, pool, budget_s=12.0):
-    """The oracle (CPU restatement of the reference's five torch ops) on the host cores."""
+def cpu_baseline(n_ent, n_rel, B, rank, pool, budget_s=15.0):
+    """The oracle (CPU restatement of the reference's five torch ops) on the host cores.
+    torch's intra-op thread count is swept (the box exposes more hardware threads than the
+    cgroup grants; oversubscription makes the small GEMMs slower) and the best is reported."""
     from oracle import score_oracle as orc
     core, R, S, O = [torch.from_numpy(x) for x in gen.make_params(n_ent, n_rel, rank, 322)]
-    threads = torch.get_num_threads()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({t for t in (avail, 64, 32, 16, 8) if t <= avail})
+    best = None
+    tried = []
     with torch.no_grad():
-        for i in range(3):
-            orc.score_ref(core, R, S, O, pool[i][0], pool[i][1])
-        t0 = time.perf_counter()
-        n = 0
-        while time.perf_counter() - t0 < budget_s:
-            h, r = pool[n % len(pool)]
-            orc.score_ref(core, R, S, O, h, r)
-            n += 1
-        dt = time.perf_counter() - t0
-    return {"value": n * B / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+        for th in cands:
+            torch.set_num_threads(th)
+            for i in range(2):
+                orc.score_ref(core, R, S, O, pool[i][0], pool[i][1])
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < budget_s / len(cands):
+                h, r = pool[n % len(pool)]
+                orc.score_ref(core, R, S, O, h, r)
+                n += 1
+            dt = time.perf_counter() - t0
+            tried.append((th, n * B / dt))
+            if best is None or n * B / dt > best[1]:
+                best = (th, n * B / dt, n, dt)
+    th, qps, n, dt = best
+    return {"value": qps, "unit": "queries/s", "cores": th, "kind": "port",
             "sample": f"{n} batches of {B} queries ({dt:.1f} s) of the same workload, torch {torch.__version__} CPU fp32, "
-                      f"{threads} threads; oracle/score_oracle.py::score_ref"}
+                      f"best of thread counts {[(a, round(b)) for a, b in tried]} ({avail} hardware threads visible); "
+                      f"oracle/score_oracle.py::score_ref"}
 
 
 def main():
@@ -68,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="wn18rr_asym_r10x200_b512_f32", choices=sorted(WORKLOADS))
     ap.add_argument("--exact", action="store_true", help="exact-fp32 MFMA score kernel instead of split-fp16")
+    ap.add_argument("--sigmoid", default=None, choices=["fast", "exact"], help="logistic of the fused epilogue (default: package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,6 +98,9 @@ def main():
     import r_tucker_amd as rt
     from r_tucker_amd import _lib
     lib = _lib.load()
+    from r_tucker_amd import ops as _ops
+    sig_mode = args.sigmoid or _ops.DEFAULT_SIGMOID
+    sflags = _lib.RTK_SCORE_SIGMOID | (_lib.RTK_SCORE_SIGMOID_FAST if sig_mode == "fast" else 0)
 
     n_ent, n_rel, B, trank, dtype = WORKLOADS[args.workload]
     a, b, c = trank
@@ -120,7 +136,7 @@ def main():
                                          _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
         else:
             _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
-                                                _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_packed_f32")
+                                                sflags, sp), "rtk_score_packed_f32")
         if ev:
             ev[1].record(stream)
         if world > 1:
@@ -157,6 +173,7 @@ def main():
         "config": {"workload": args.workload, "entities": n_ent, "relations": n_rel, "rank": list(trank),
                    "batch": B, "scores_per_query": n_ent,
                    "score_kernel": "exact_f32_mfma" if args.exact else "split_fp16_mfma",
+                   "sigmoid": "exact" if args.exact else sig_mode,
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
         "scores_per_s": args.steps * B * n_ent / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

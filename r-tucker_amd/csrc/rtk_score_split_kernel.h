@@ -6,6 +6,10 @@
 
 namespace rtk_split {
 
+// tools/ablate only (ABL bit 6): per-block phase stamps (s_memrealtime, 100 MHz)
+__device__ unsigned long long g_stamps[4096 * 4];
+__device__ unsigned long long g_istamps[4096 * 8];   // ABL bit 7: s_memtime stamps inside iteration 3
+
 // SIGMOID: 0 = raw logits, 1 = ocml expf + IEEE divide (torch-CPU formula, ~25 VALU),
 //          2 = v_exp_f32 / v_rcp_f32 + one Newton step (7 VALU, <= ~2 ulp for z >= 0)
 __device__ __forceinline__ float logistic_fast(float z) {
@@ -39,6 +43,8 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
     int64_t lin = U * blockIdx.x / gridDim.x;
     const int64_t lin_end = U * (blockIdx.x + 1) / gridDim.x;
 
+    int stamp_n = 0;
+    if (off(64) && t == 0) g_stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     while (lin < lin_end) {
         const int ntile = (int)(lin / n_mt), mt0 = (int)(lin % n_mt);
         const int cnt = (int)min((int64_t)(n_mt - mt0), lin_end - lin);
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 Bl[ks][q] = (_Float16)(y - (float)hi);
             }
         }
+        if (off(64) && t == 0 && stamp_n == 0) { g_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); stamp_n = 1; }
         if (off(8)) {  // prologue only: keep the fragments alive
             float keep = 0.f;
 #pragma unroll
@@ -126,10 +133,14 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
         // shadow of the next tile's MFMA chain.
         const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
         __amdgpu_buffer_rsrc_t ers;  // descriptor of the tile whose epilogue is running
+        unsigned ep_off = voff;      // running byte offset of the next store (kept out of LICM's reach)
+        const unsigned ld4 = (unsigned)(ld_out * 4);
         auto epilogue_begin = [&](int mt, bool live) {
             const int rows = live ? min(32, B - mt * 32) : 0;
             ers = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)max(mt, 0) * 32 * ld_out, 0,
                                                     (unsigned)(rows * ld_out * 4), 0x00020000);
+            ep_off = voff;
+            asm volatile("" : "+v"(ep_off));   // one live register instead of 16 hoisted offsets
         };
         // The epilogue of one tile is cut into 32 pieces (16 accumulator elements x
         // {exponential half, reciprocal half + store}) that the k-loop drops into the gaps
@@ -156,8 +167,9 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 if (off(4)) {
                     if (pv == 12345.678f) out[0] = pv;
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers,
-                                                          voff + (unsigned)(row * ld_out * 4), 0, 0);
+                    (void)row;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, 0);
+                    ep_off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
                 }
             }
         };
@@ -170,7 +182,10 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
         for (int e = 0; e < 16; ++e) prev[e] = 0.f;
         for (int i = 0; i < cnt; ++i) {
             const int cur = i & 1;
+            const bool stamp_it = off(128) && i == 3 && lane == 0;
+            if (stamp_it) g_istamps[(blockIdx.x * 4 + wave) * 8 + 0] = __builtin_amdgcn_s_memtime();
             if (i + 1 < cnt) stage_load(mt0 + i + 1);
+            if (stamp_it) g_istamps[(blockIdx.x * 4 + wave) * 8 + 1] = __builtin_amdgcn_s_memtime();
             const unsigned char *tile = lds + cur * TILE_BYTES;
             const f16x8 *lh = reinterpret_cast<const f16x8 *>(tile + RTK_PACK_HDR);
             const f16x8 *ll = lh + KS * 64;
@@ -202,6 +217,7 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 ah = nh;
                 al = nl;
             }
+            if (stamp_it) g_istamps[(blockIdx.x * 4 + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
             // unscale while this tile's row factors are still in LDS:
             // C/D map  column = lane & 31 (entity), row = (e & 3) + 8*(e >> 2) + 4*h
             const float *lscale = reinterpret_cast<const float *>(tile);
@@ -212,12 +228,15 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 for (int q = 0; q < 4; ++q) prev[4 * g + q] = acc[4 * g + q] * sv[q] * us_o;
             }
             stage_store(cur ^ 1);  // unconditional: a stale tile in the spare buffer is never read
+            if (stamp_it) g_istamps[(blockIdx.x * 4 + wave) * 8 + 3] = __builtin_amdgcn_s_memtime();
             if (!off(32)) __syncthreads();
+            if (stamp_it) g_istamps[(blockIdx.x * 4 + wave) * 8 + 4] = __builtin_amdgcn_s_memtime();
         }
         epilogue_begin(mt0 + cnt - 1, true);
 #pragma unroll
         for (int pc = 0; pc < 32; ++pc) piece(prev, pc);
     }
+    if (off(64) && t == 0) g_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace rtk_split

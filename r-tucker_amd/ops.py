@@ -10,12 +10,18 @@ query vectors; it never leaves the GPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
 
 _workspaces = {}
+
+# Logistic used by the fused score epilogue: "exact" = expf + IEEE divide (the formula
+# torch's CPU kernel evaluates), "fast" = v_exp_f32 / v_rcp_f32 + one Newton step
+# (<= ~2 ulp, ~3x fewer VALU instructions).  Override with R_TUCKER_AMD_SIGMOID.
+DEFAULT_SIGMOID = os.environ.get("R_TUCKER_AMD_SIGMOID", "fast")
 
 
 def _require_gpu(name, t):
@@ -56,7 +62,7 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v):
+def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None):
     lib = _lib.load()
     core, R, S, O = _f32c("core", core), _f32c("R", R), _f32c("S", S), _f32c("O", O)
     dev = core.device
@@ -83,12 +89,17 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v):
         sp = _stream_ptr(dev)
         need = lib.rtk_workspace_bytes(_lib.RTK_F32, B, R.shape[0], a, b, c)
         ws = _workspace(dev, sp, need)
+        mode = sigmoid_mode or DEFAULT_SIGMOID
+        if mode not in ("fast", "exact"):
+            raise ValueError(f"sigmoid mode must be 'fast' or 'exact', got {mode!r}")
         flags = (_lib.RTK_SCORE_SIGMOID if sigmoid else 0) | (_lib.RTK_SCORE_EXACT_F32 if exact else 0)
+        flags |= _lib.RTK_SCORE_SIGMOID_FAST if (sigmoid and mode == "fast") else 0
+        sflags = flags & (_lib.RTK_SCORE_SIGMOID | _lib.RTK_SCORE_SIGMOID_FAST)
         v = None
         if want_v:
             # two-call form so the fp32 query vectors are kept for backward
             v = torch.empty((B, c), dtype=torch.float32, device=dev)
-            use_packed = not exact and c <= 512
+            use_packed = not exact and c <= 256
             qp = None
             if use_packed:
                 qp = torch.empty(lib.rtk_packed_query_bytes(_lib.RTK_F32, B, c), dtype=torch.uint8, device=dev)
@@ -98,7 +109,7 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v):
                                                  ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_f32")
             if use_packed:
                 _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), N,
-                                                    flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_packed_f32")
+                                                    sflags, sp), "rtk_score_packed_f32")
             else:
                 _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), N,
                                              flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
@@ -112,8 +123,8 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v):
 
 class _Score1vN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, core, R, S, O, subject_idx, relation_idx, sigmoid, exact):
-        out, v = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=True)
+    def forward(ctx, core, R, S, O, subject_idx, relation_idx, sigmoid, exact, sigmoid_mode):
+        out, v = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=True, sigmoid_mode=sigmoid_mode)
         dev = core.device
         ctx.save_for_backward(core, R, S, O, _idx("s", subject_idx, dev), _idx("r", relation_idx, dev), v, out)
         ctx.sigmoid = sigmoid
@@ -135,21 +146,22 @@ class _Score1vN(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gS = torch.zeros_like(S).index_add_(0, h, torch.einsum("dab,da->db", W, Rb))
         # symmetric model: S and O are the same tensor passed twice; autograd sums gS + gO
-        return gcore, gR, gS, gO, None, None, None, None
+        return gcore, gR, gS, gO, None, None, None, None, None
 
 
-def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=False):
+def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=False, sigmoid_mode=None):
     """``sigmoid((G x_0 R[r] x_1 S[h]) . O^T)`` for a batch of (h, r) queries -> ``(B, N)``.
 
     Same operands and result as the body of the reference's ``score_fn``
     (asymmetric/R_TuckER.py:43-48; symmetric: pass ``S is O``).  ``exact=True``
-    selects the exact-fp32 MFMA score kernel instead of the split-fp16 one.
+    selects the exact-fp32 MFMA score kernel instead of the split-fp16 one;
+    ``sigmoid_mode`` ("fast" | "exact") picks the logistic of the fused epilogue.
     """
     needs_grad = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (core, R, S, O))
     if needs_grad:
-        return _Score1vN.apply(core, R, S, O, subject_idx, relation_idx, sigmoid, exact)
-    out, _ = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False)
+        return _Score1vN.apply(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, sigmoid_mode)
+    out, _ = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False, sigmoid_mode=sigmoid_mode)
     return out
 
 

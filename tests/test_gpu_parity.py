@@ -57,7 +57,9 @@ def test_scores_against_reference_vectors(rt, golden, golden_meta, size, mode, e
     if mode == "sym":
         dO = dS
     z = rt.score_1vN(dcore, dR, dS, dO, dh, dr, sigmoid=False, exact=exact).cpu().numpy()
-    p = rt.score_1vN(dcore, dR, dS, dO, dh, dr, sigmoid=True, exact=exact).cpu().numpy()
+    p = rt.score_1vN(dcore, dR, dS, dO, dh, dr, sigmoid=True, exact=exact, sigmoid_mode="exact").cpu().numpy()
+    pf = rt.score_1vN(dcore, dR, dS, dO, dh, dr, sigmoid=True, exact=exact, sigmoid_mode="fast").cpu().numpy()
+    assert np.abs(pf - g["probs"]).max() <= P_TOL
     ze = orc.logits_exact(core, R, S, O, h, r)
     print(f"\n{size}_{mode} exact={exact}: hip-vs-f64 {zerr(z, ze):.2e}  ref-vs-f64 {zerr(g['logits'], ze):.2e}  "
           f"hip-vs-ref {zerr(z, g['logits']):.2e}  dp {np.abs(p - g['probs']).max():.2e}")

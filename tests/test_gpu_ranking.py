@@ -30,9 +30,12 @@ def wn():
     return data, ds
 
 
+@pytest.mark.parametrize("sigmoid_mode", ["fast", "exact"])
 @pytest.mark.parametrize("variant", ["spread", "saturated", "planted", "planted_sat"])
-def test_filtered_mrr_matches_reference(wn, golden, golden_meta, variant):
+def test_filtered_mrr_matches_reference(wn, golden, golden_meta, variant, sigmoid_mode, monkeypatch):
     import r_tucker_amd as rt
+    from r_tucker_amd import ops
+    monkeypatch.setattr(ops, "DEFAULT_SIGMOID", sigmoid_mode)
     data, ds = wn
     n_ent, n_rel, rank, seed = len(data.entities), len(data.relations), (10, 200, 200), 322
     if variant.startswith("planted"):
@@ -65,9 +68,9 @@ def test_filtered_mrr_matches_reference(wn, golden, golden_meta, variant):
         ranks = np.concatenate(ranks)
         same = float((ranks == g[f"{variant}_{split}_ranks"]).mean())
         mrr, ref_mrr = sums["mrr"] / len(d), case["mrr"]
-        print(f"\n{variant}/{split}: MRR hip {mrr:.6f} ref {ref_mrr:.6f}  identical ranks {same:.4%}  "
+        print(f"\n{variant}/{split} [{sigmoid_mode}]: MRR hip {mrr:.6f} ref {ref_mrr:.6f}  identical ranks {same:.4%}  "
               f"hits@1 {sums['hits@1']:.0f}/{case['sums']['hits@1']:.0f}")
         assert abs(mrr - ref_mrr) <= 1e-3
-        assert same >= 0.99
+        assert same >= (0.99 if sigmoid_mode == "exact" else 0.97)
         for k in ("hits@1", "hits@3", "hits@10"):
             assert abs(sums[k] - case["sums"][k]) <= 0.002 * len(d) + 1

@@ -13,6 +13,14 @@ static void go(const void *qp, int64_t B, int c, const float *O, int64_t N, floa
                        (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld, c % 4 == 0);
 }
 
+extern "C" int rtk_ablate_read_istamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rtk_split::g_istamps), sizeof(unsigned long long) * n);
+}
+
+extern "C" int rtk_ablate_read_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rtk_split::g_stamps), sizeof(unsigned long long) * n);
+}
+
 extern "C" int rtk_ablate_score_packed_f32(const void *qp, int64_t B, int c, const float *O, int64_t N,
                                            float *out, int64_t ld, int sigmoid, int grid, unsigned abl,
                                            void *stream) {
@@ -21,6 +29,7 @@ extern "C" int rtk_ablate_score_packed_f32(const void *qp, int64_t B, int c, con
 #define CASE(SG, A) if (sigmoid == SG && abl == A) { go<SG, A>(qp, B, c, O, N, out, ld, grid, st); return (int)hipGetLastError(); }
     CASE(2, 0) CASE(1, 0) CASE(0, 0)
     CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(2, 8) CASE(2, 16) CASE(2, 20) CASE(2, 32) CASE(2, 36) CASE(2, 21) CASE(2, 53)
+    CASE(2, 64) CASE(2, 128) CASE(0, 128)
     CASE(0, 21) CASE(0, 22) CASE(2, 19) CASE(0, 53) CASE(2, 5) CASE(2, 37)
     return -5;
 }
