@@ -114,8 +114,9 @@ def main():
     hi = min(lo + n_loc, n_ent)
     O_loc = torch.zeros((n_loc, c), dtype=torch.float32, device=dev)
     O_loc[: hi - lo] = O[lo:hi]                       # last shard zero-padded to equal size
-    out = torch.empty((B, n_loc), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, B, n_loc), dtype=torch.float32, device=dev) if world > 1 else None
+    # rank p's (B, n_loc) block is slot p of the gather buffer: the kernel writes its block in place
+    gathered = torch.empty((world, B, n_loc), dtype=torch.float32, device=dev)
+    out = gathered[rank]
 
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
@@ -140,7 +141,9 @@ def main():
         if ev:
             ev[1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+            dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))   # in place: input = own slot
+            if ev:
+                ev[2].record(stream)
 
     def barrier():
         if world > 1:
@@ -149,7 +152,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -161,7 +164,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if world > 1 else None
     # algorithmic bytes of ONE score-kernel launch: read the O shard once, write the scores once,
     # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
     alg_bytes = n_loc * c * 4 + B * n_loc * 4 + B * c * 4
@@ -181,6 +185,14 @@ def main():
                      "kernel": "score_split_kernel" if not args.exact else "gemm_f32_kernel",
                      "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
     }
+    if world > 1:
+        # the exchange step: every rank receives (P-1) blocks of B*n_loc fp32 over xGMI
+        # (7 links x ~153 GB/s per GPU, MI355X guide); reported next to the shard-local rate
+        recv = (world - 1) * B * n_loc * 4
+        result["exchange"] = {"collective": "all_gather_into_tensor (RCCL, in place)", "ms": gather_ms,
+                              "bytes_received_per_gpu": recv, "achieved_GBps": recv / (gather_ms * 1e-3) / 1e9,
+                              "xgmi_peak_GBps": 7 * 153.0, "frac": recv / (gather_ms * 1e-3) / 1e9 / (7 * 153.0),
+                              "shard_local_queries_per_s": B / (kern_ms * 1e-3)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(n_ent, n_rel, B, trank, pool_cpu)
     if rank == 0:

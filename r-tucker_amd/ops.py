@@ -62,7 +62,7 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None):
+def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None, out=None):
     lib = _lib.load()
     core, R, S, O = _f32c("core", core), _f32c("R", R), _f32c("S", S), _f32c("O", O)
     dev = core.device
@@ -82,7 +82,12 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
     if b != c:
         # asymmetric/R_TuckER.py:46: .view(-1, b) of a (B,1,c) tensor
         raise RuntimeError(f"shape '[-1, {b}]' is invalid for input of size {B * c}")
-    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    elif (tuple(out.shape) != (B, N) or out.dtype != torch.float32 or out.device != dev or out.stride(1) != 1
+          or out.stride(0) < N):
+        raise RuntimeError(f"out must be a float32 ({B}, {N}) tensor on {dev} with unit column stride")
+    ld = out.stride(0) if B > 1 else N
     if B == 0:
         return out, None
     with torch.cuda.device(dev):
@@ -108,15 +113,15 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
                                                  v.data_ptr(), qp.data_ptr() if use_packed else None,
                                                  ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_f32")
             if use_packed:
-                _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), N,
+                _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
                                                     sflags, sp), "rtk_score_packed_f32")
             else:
-                _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), N,
+                _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
                                              flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
         else:
             _lib.check(lib.rtk_score_1vN_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0],
                                              S.data_ptr(), S.shape[0], O.data_ptr(), N,
-                                             r.data_ptr(), h.data_ptr(), B, out.data_ptr(), N, flags,
+                                             r.data_ptr(), h.data_ptr(), B, out.data_ptr(), ld, flags,
                                              ws.data_ptr(), ws.numel(), sp), "rtk_score_1vN_f32")
     return out, v
 
@@ -162,6 +167,15 @@ def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=Fals
     if needs_grad:
         return _Score1vN.apply(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, sigmoid_mode)
     out, _ = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False, sigmoid_mode=sigmoid_mode)
+    return out
+
+
+def score_1vN_into(core, R, S, O, subject_idx, relation_idx, out, sigmoid=True, exact=False, sigmoid_mode=None):
+    """``score_1vN`` writing into a caller-provided (B, N) buffer (row stride >= N); no autograd.
+    Used by the entity-sharded scorer so the local block lands in its all-gather slot."""
+    with torch.no_grad():
+        _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False,
+                 sigmoid_mode=sigmoid_mode, out=out)
     return out
 
 

@@ -1,0 +1,97 @@
+"""Entity-sharded 1-vs-all scoring across the GPUs of one node (one process per GPU).
+
+The reference is single-device; this is the multi-GPU form BASELINE.json's north_star
+asks for: the entity matrix O (asymmetric) / E (symmetric) is partitioned into
+contiguous row blocks, one per rank; every rank scores the whole (h, r) batch
+against ITS block with the local HIP kernels -- score columns are independent per
+entity, ``Z[:, J_p] = v . O[J_p, :]^T`` -- and the per-shard score blocks are
+exchanged with ONE collective, an all-gather (RCCL over xGMI when the process group
+is "nccl").  The core tensor, the relation matrix and the subject-lookup matrix stay
+replicated (they are small next to the B x N score block).
+
+Layout.  Shards are padded to equal size ``n_loc = ceil(N / P)``; the all-gather
+concatenates along dim 0, so the gathered buffer is ``(P, B, n_loc)`` with rank p's
+block in slot p.  ``scores_rowmajor`` turns it into the reference's ``(B, N)``
+(one strided copy); consumers that can work shard-wise should use the gathered
+buffer directly (``view_BPn``) and skip that copy.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class EntityShards:
+    """Row partition of ``n_ent`` entities over ``world`` ranks."""
+
+    def __init__(self, n_ent: int, world: int):
+        if n_ent <= 0 or world <= 0:
+            raise ValueError("n_ent and world must be positive")
+        self.n_ent, self.world = int(n_ent), int(world)
+        self.n_loc = -(-self.n_ent // self.world)   # ceil: every shard padded to this many rows
+
+    def bounds(self, rank: int):
+        lo = min(rank * self.n_loc, self.n_ent)
+        return lo, min(lo + self.n_loc, self.n_ent)
+
+    def take(self, full: torch.Tensor, rank: int) -> torch.Tensor:
+        """This rank's (n_loc, c) block of a full (N, c) matrix, zero-padded at the end."""
+        lo, hi = self.bounds(rank)
+        out = torch.zeros((self.n_loc,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+        out[: hi - lo] = full[lo:hi]
+        return out
+
+
+class ShardedEntityScorer:
+    """``score(...)`` = the reference's ``score_fn`` with O row-sharded over a process group.
+
+    ``local_score(core, R, S, O_loc, h, r, out=...)`` computes the (B, n_loc) block; the
+    default is the HIP path (``ops.score_1vN_into``).  Tests inject a CPU function to
+    exercise the sharding / gather logic under the gloo backend.
+    """
+
+    def __init__(self, n_ent: int, group=None, local_score=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.shards = EntityShards(n_ent, self.world)
+        if local_score is None:
+            from .ops import score_1vN_into
+            local_score = score_1vN_into
+        self.local_score = local_score
+        self._gathered = None
+
+    def local_block(self, full_entity_matrix: torch.Tensor) -> torch.Tensor:
+        return self.shards.take(full_entity_matrix, self.rank)
+
+    def _buffer(self, B, device, dtype):
+        need = (self.world, B, self.shards.n_loc)
+        g = self._gathered
+        if g is None or tuple(g.shape) != need or g.device != device or g.dtype != dtype:
+            g = torch.empty(need, dtype=dtype, device=device)
+            self._gathered = g
+        return g
+
+    def score_gathered(self, core, R, S, O_loc, subject_idx, relation_idx, **kw) -> torch.Tensor:
+        """All ranks' score blocks, ``(P, B, n_loc)``; slot p = rank p's entities.
+        Columns past the real entity count in the last shard are padding (sigmoid(0) = 0.5)."""
+        B = int(subject_idx.numel())
+        g = self._buffer(B, core.device, core.dtype)
+        mine = g[self.rank]                                   # (B, n_loc) view: the kernel writes in place
+        self.local_score(core, R, S, O_loc, subject_idx, relation_idx, out=mine, **kw)
+        if self.world > 1:
+            # in-place all-gather: input is the rank-th slice of the output buffer
+            dist.all_gather_into_tensor(g.view(-1), mine.view(-1), group=self.group)
+        return g
+
+    def view_BPn(self, gathered: torch.Tensor) -> torch.Tensor:
+        """(B, P, n_loc) view of the gathered buffer: [d, p, i] = score of entity p*n_loc + i."""
+        return gathered.permute(1, 0, 2)
+
+    def scores_rowmajor(self, gathered: torch.Tensor) -> torch.Tensor:
+        """The reference's (B, N) layout (copies)."""
+        B = gathered.shape[1]
+        return self.view_BPn(gathered).reshape(B, self.world * self.shards.n_loc)[:, : self.shards.n_ent].contiguous()
+
+    def score(self, core, R, S, O_loc, subject_idx, relation_idx, **kw) -> torch.Tensor:
+        return self.scores_rowmajor(self.score_gathered(core, R, S, O_loc, subject_idx, relation_idx, **kw))
