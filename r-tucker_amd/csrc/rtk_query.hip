@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(const int64_t *__restrict__ 
 // M[u, n] = sum_a R[rel(u), a] * G[a, n],  n in [0, b*c).  Streaming VALU kernel for
 // small relation rank (a <= 32: WN18RR has a = 10): each thread owns one float4 of
 // n for UT relations, so every G element is loaded once per UT relations.
-constexpr int UT = 8;
+constexpr int UT = 4;
 template <bool VEC>
 __global__ __launch_bounds__(256) void tables_kernel(const float *__restrict__ G, int a, int64_t bc,
                                                      const float *__restrict__ R,
@@ -79,20 +79,31 @@ __global__ __launch_bounds__(256) void tables_kernel(const float *__restrict__ G
     for (int u = 0; u < UT; ++u)
 #pragma unroll
         for (int j = 0; j < W; ++j) acc[u][j] = 0.f;
-    for (int ai = 0; ai < a; ++ai) {
-        float g[W];
-        if (VEC) {
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(G + (int64_t)ai * bc + n);
+    // the loads of 8 consecutive relation-rank slices are issued together (independent of the
+    // FMAs): with one load per trip the kernel is a chain of `a` exposed L2 latencies
+    for (int a0 = 0; a0 < a; a0 += 8) {
+        float g[8][W];
 #pragma unroll
-            for (int j = 0; j < W; ++j) g[j] = x[j];
-        } else {
-            g[0] = G[(int64_t)ai * bc + n];
+        for (int k = 0; k < 8; ++k) {
+            const int ai = min(a0 + k, a - 1);
+            if (VEC) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(G + (int64_t)ai * bc + n);
+#pragma unroll
+                for (int j = 0; j < W; ++j) g[k][j] = x[j];
+            } else {
+                g[k][0] = G[(int64_t)ai * bc + n];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < UT; ++u) {
-            const float rv = Rs[u * 64 + ai];
+        for (int k = 0; k < 8; ++k) {
+            if (a0 + k < a) {
 #pragma unroll
-            for (int j = 0; j < W; ++j) acc[u][j] = fmaf(rv, g[j], acc[u][j]);
+                for (int u = 0; u < UT; ++u) {
+                    const float rv = Rs[u * 64 + a0 + k];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) acc[u][j] = fmaf(rv, g[k][j], acc[u][j]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
         for (int j = 0; j < W; ++j) acc[j] = 0.f;
         if (active) {
             const int gstep = (npass == 1) ? ngroups : 1;
-#pragma unroll 4
+#pragma unroll 8
             for (int bi = g; bi < b; bi += gstep) {
                 const float sv = s_row[bi];
                 if (VEC) {

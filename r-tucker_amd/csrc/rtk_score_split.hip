@@ -16,6 +16,8 @@
 // A fragments (conflict-free ds_read_b128) and issues 3*KS MFMAs into one 32x32
 // accumulator, and the epilogue unscales, applies the logistic and stores
 // 128-B-contiguous row segments (lane = entity) straight from the accumulator.
+#include <stdlib.h>
+
 #include "rtk_common.h"
 #include "rtk_pack.h"
 
@@ -51,6 +53,19 @@ void launch_ks(const unsigned char *qp, int B, const float *O, int N, int c, flo
 
 }  // namespace
 
+bool rtk_score_ws_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
+                         int sg, bool o_vec, hipStream_t st);
+
+// RTK_SCORE_KERNEL=v3 forces the two-workgroups-per-CU kernel (A/B comparisons)
+static bool use_ws_kernel() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RTK_SCORE_KERNEL");
+        v = (e && e[0] == 'v' && e[1] == '3') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int rtk_split_ksteps_supported(int c) {
     const int ks = (c + 15) / 16;
     return ks >= 1 && ks <= 16;   // two fp16 planes of B fragments must fit the register file next to the pipeline state
@@ -71,6 +86,8 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
     const bool o_vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
     const int B = (int)batch, N = (int)n_local;
     const unsigned char *qp = (const unsigned char *)q_packed;
+    if (use_ws_kernel() && rtk_score_ws_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st))
+        return rtk_check_launch("rtk_score_packed_f32");
     // the packed planes were written for exactly `ks` k-steps (tile stride), so the
     // instantiation must match exactly.
 #define RTK_KS(K_, W_) \

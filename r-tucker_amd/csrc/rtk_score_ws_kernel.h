@@ -1,0 +1,373 @@
+// Split-fp16 score kernel, wave-specialised persistent form (c <= 208, i.e. KS <= 13).
+//
+//   out[d, j] = logistic( v[d,:] . O[j,:] )          reference: asymmetric/R_TuckER.py:47-48
+//
+// One 512-thread workgroup per CU, resident for the whole launch, two waves per SIMD with
+// different jobs (the matrix pipe and the VALU/VMEM pipes are separate, so a wave that only
+// issues MFMAs and a wave that only issues vector/memory work overlap on one SIMD for free):
+//
+//   waves 0-3  "M"  own 32 entity columns each: B fragments (hi/lo fp16 of their O rows) stay
+//                   in registers; per query tile they read the A fragments from LDS, issue the
+//                   3*KS dependent MFMAs, and hand the unscaled 32x32 fp32 result to a helper
+//                   through an LDS exchange slot (one tile behind, inside the MFMA gaps).
+//   waves 4-7  "H"  do everything else: stream the packed query tiles global -> registers ->
+//                   LDS two tiles ahead, apply the logistic and store the scores of the tile
+//                   the M waves finished two iterations ago (branch-free buffer stores, 128-B
+//                   row segments), and prefetch the NEXT 128-row tile of O (fully coalesced
+//                   16-B loads, all in flight) so that switching entity tiles costs one LDS
+//                   round trip instead of an exposed HBM latency.
+//
+// LDS: [2 x query tile (staging, double buffered)] [raw O tile 128 x c fp32; during a sweep the
+// same region holds the 2 x 16 KiB accumulator exchange slots].  One barrier per iteration.
+// Work split: the linearised (entity tile x query tile) space is cut evenly over the grid.
+#pragma once
+#include "rtk_common.h"
+#include "rtk_pack.h"
+
+namespace rtk_ws {
+
+__device__ __forceinline__ float logistic_fast(float z) {
+    const float t = fminf(z * -1.4426950408889634f, 126.0f);  // exp2 argument; clamp keeps 1+e finite
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float d = 1.0f + e;
+    const float p = __builtin_amdgcn_rcpf(d);
+    return fmaf(p, fmaf(-d, p, 1.0f), p);
+}
+
+// tools/ablate only: cycle stamps (STAMP template flag)
+__device__ unsigned long long g_ws_stamps[256 * 8 * 8];
+
+constexpr int EX_BYTES = 4 * 4 * 64 * 16;  // one exchange buffer: 4 M waves x 16 accumulator regs x 64 lanes x f32
+
+template <int KS>
+__host__ __device__ constexpr int tile_bytes() { return RTK_PACK_HDR + 2 * KS * 1024; }
+
+// dynamic LDS the kernel needs for entity rank c
+template <int KS>
+inline size_t lds_bytes(int c) {
+    const size_t oreg = (size_t)128 * c * 4;
+    return 2 * (size_t)tile_bytes<KS>() + (oreg > 2 * (size_t)EX_BYTES ? oreg : 2 * (size_t)EX_BYTES);
+}
+
+// Both roles walk the same (entity tile, query tile) schedule and meet at the same barriers;
+// they are separate functions so each gets its own register allocation (the M waves keep
+// 2*KS B fragments alive, the H waves a whole raw O tile).
+struct Sched {
+    int B, N, c, n_mt;
+    int64_t lin, lin_end;
+    __device__ __forceinline__ bool next(int &ntile, int &mt0, int &cnt, bool &more) {
+        if (lin >= lin_end) return false;
+        ntile = (int)(lin / n_mt);
+        mt0 = (int)(lin % n_mt);
+        cnt = (int)min((int64_t)(n_mt - mt0), lin_end - lin);
+        lin += cnt;
+        more = lin < lin_end;
+        return true;
+    }
+};
+
+template <int KS, bool STAMP, unsigned XP>
+__device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict__ q_packed, unsigned char *stg,
+                                       unsigned char *oreg, bool o_vec, int lane, int w4, int ht) {
+    constexpr int TILE_BYTES = tile_bytes<KS>();
+    constexpr int CHUNKS = TILE_BYTES / 16;
+    constexpr int NLD = (CHUNKS + 255) / 256;   // staging 16-B chunks per M thread
+    constexpr int PF = KS < 3 ? KS : 3;         // A-fragment prefetch distance (k-steps): LDS latency > one k-step of MFMAs
+    if (XP & 1) __builtin_amdgcn_s_setprio(3);
+    const int r = lane & 31, h = lane >> 5, c = sc.c;
+    // The M waves also stage the query tiles (global -> registers at the top of an iteration,
+    // -> LDS in its last MFMA gaps): they issue no stores, so a staged load never queues behind
+    // a score store in the in-order vmcnt stream (the H waves' stores take ~1 us to retire).
+    u32x4 sreg[NLD];
+    // buffer loads: the tile base goes in the scalar offset, the per-thread part is a constant
+    // VGPR, chunks past the tile (last, partial round) fall outside num_records and read 0
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(q_packed), 0, (unsigned)(sc.n_mt * TILE_BYTES), 0x00020000);
+    auto stage_load1 = [&](int mt, int i) {   // one 16-B chunk per thread (a 1-KiB wave instruction)
+        const unsigned vo = (i + 1 < NLD || i * 256 + ht < CHUNKS) ? (unsigned)(ht * 16) : 0x80000000u;
+        sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, mt * TILE_BYTES + i * 4096, 0);
+    };
+    int ntile, mt0, cnt;
+    bool more;
+    while (sc.next(ntile, mt0, cnt, more)) {
+        __syncthreads();                             // S1: raw O tile visible in LDS
+        f16x8 Bh[KS], Bl[KS];
+        float us_o;
+        {
+            const float *lrow = reinterpret_cast<const float *>(oreg) + (w4 * 32 + r) * c;
+            auto frag8 = [&](int ks, float (&x)[8]) {   // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
+                const int k = 16 * ks + 8 * h;
+                if (o_vec) {  // c % 4 == 0: 16-B aligned rows; a float4 is wholly inside or outside
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                    if (k + 4 <= c) a = *reinterpret_cast<const f32x4 *>(lrow + k);
+                    if (k + 8 <= c) b = *reinterpret_cast<const f32x4 *>(lrow + k + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        x[q] = a[q];
+                        x[4 + q] = b[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[q] = (k + q < c) ? lrow[k + q] : 0.f;
+                }
+            };
+            float mx = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float x[8];
+                frag8(ks, x);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mx = fmaxf(mx, fabsf(x[q]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const int sh = rtk_pack_shift(mx);
+            const float up = ldexpf(1.0f, sh);
+            us_o = ldexpf(1.0f, -sh);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float x[8];
+                frag8(ks, x);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float y = x[q] * up;
+                    const _Float16 hi = (_Float16)y;
+                    Bh[ks][q] = hi;
+                    Bl[ks][q] = (_Float16)(y - (float)hi);
+                }
+            }
+        }
+        __syncthreads();                             // S2: tile mt0 staged, O region free for the exchange
+
+        f32x16 prev;
+        f32x4 svp[4];                                // row unscale factors of the tile in `prev`
+#pragma unroll
+        for (int e = 0; e < 16; ++e) prev[e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) svp[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < cnt + 2; ++i) {
+            const bool st = STAMP && i == 5 && lane == 0;
+            unsigned long long *sp = g_ws_stamps + (blockIdx.x * 8 + w4) * 8;
+            if (st) sp[0] = __builtin_amdgcn_s_memtime();
+            f32x4 *exw = reinterpret_cast<f32x4 *>(oreg + ((i + 1) & 1) * EX_BYTES + w4 * 4096);   // slot of tile i-1
+            if (i < cnt) {
+                const unsigned char *tile = stg + (i & 1) * TILE_BYTES;
+                const f16x8 *lh = reinterpret_cast<const f16x8 *>(tile + RTK_PACK_HDR);
+                const f16x8 *ll = lh + KS * 64;
+                // two accumulators, MFMAs alternating between them: a single dependent chain
+                // issues one 32x32x16 MFMA per ~40 cycles, two independent ones per ~35
+                f32x16 acc, acc2;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = acc2[e] = 0.f;
+                const int mt_next = (i + 1 < cnt) ? mt0 + i + 1 : mt0 + i;   // (re)load something valid: branch-free
+                if (st) sp[3] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+                for (int li = 0; li < NLD; ++li) stage_load1(mt_next, li);   // tile i+1: all loads up front (L2 latency ~1k cycles)
+                u32x4 *sdst = reinterpret_cast<u32x4 *>(stg + ((i + 1) & 1) * TILE_BYTES);
+                f16x8 fa[PF], fl[PF];                // A fragments PF k-steps ahead
+#pragma unroll
+                for (int p = 0; p < PF; ++p) {
+                    fa[p] = lh[p * 64 + lane];
+                    fl[p] = ll[p * 64 + lane];
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f16x8 ah = fa[ks % PF], al = fl[ks % PF];
+                    if (ks + PF < KS) {
+                        fa[ks % PF] = lh[(ks + PF) * 64 + lane];
+                        fl[ks % PF] = ll[(ks + PF) * 64 + lane];
+                    }
+                    // sched_barrier(0) pins the written order: the scheduler otherwise sinks every
+                    // fragment read next to its MFMA (one LDS latency per k-step, 2.4x the chain time)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((3 * ks) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], acc, 0, 0, 0);
+                    if (ks < 4) {                    // hand-over of tile i-1 rides in the first MFMA gaps
+                        f32x4 z;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) z[q] = prev[4 * ks + q] * svp[ks][q] * us_o;
+                        exw[ks * 64 + lane] = z;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((3 * ks + 1) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc, 0, 0, 0);
+                    if (st && ks == KS - NLD) sp[4] = __builtin_amdgcn_s_memtime();
+                    if (ks >= KS - NLD && ks - (KS - NLD) < NLD) {   // staged tile i+1 -> LDS in the last gaps
+                        const int si = ks - (KS - NLD);
+                        const int ch = si * 256 + ht;
+                        if (si + 1 < NLD || ch < CHUNKS) sdst[ch] = sreg[si];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((3 * ks + 2) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (st) sp[5] = __builtin_amdgcn_s_memtime();
+                if (KS < NLD) {
+#pragma unroll
+                    for (int si = 0; si < NLD - (KS < NLD ? KS : NLD); ++si) {   // tiny ranks: leftovers after the chain
+                        const int ch = (si + KS) * 256 + ht;
+                        if (si + KS + 1 < NLD || ch < CHUNKS) sdst[ch] = sreg[si + KS];
+                    }
+                }
+#pragma unroll
+                for (int g = (KS < 4 ? KS : 4); g < 4; ++g) {
+                    f32x4 z;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[q] = prev[4 * g + q] * svp[g][q] * us_o;
+                    exw[g * 64 + lane] = z;
+                }
+                // keep this tile's row factors: its LDS buffer is restaged during the next iteration
+                const float *lscale = reinterpret_cast<const float *>(tile);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) svp[g] = *reinterpret_cast<const f32x4 *>(lscale + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) prev[e] = acc[e] + acc2[e];
+                if (st) sp[6] = (unsigned long long)__builtin_amdgcn_s_memtime() + (unsigned long long)(prev[0] == 12345.f);
+            } else if (i == cnt) {                   // drain: hand over the last tile
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 z;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[q] = prev[4 * g + q] * svp[g][q] * us_o;
+                    exw[g * 64 + lane] = z;
+                }
+            }
+            if (st) sp[1] = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            if (st) sp[2] = __builtin_amdgcn_s_memtime();
+        }
+    }
+    if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+}
+
+template <int KS, int SIGMOID, bool STAMP, unsigned XP>
+__device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict__ q_packed,
+                                       const float *__restrict__ O, float *__restrict__ out, int64_t ld_out,
+                                       unsigned char *stg, unsigned char *oreg, int lane, int w4, int ht) {
+    constexpr int TILE_BYTES = tile_bytes<KS>();
+    constexpr int CHUNKS = TILE_BYTES / 16;
+    constexpr int NLD = (CHUNKS + 255) / 256;   // staging 16-B chunks per helper thread
+    constexpr int NOR = 2 * KS;                 // raw O 16-B pieces per helper thread (32*c/256 <= 2*KS)
+    const int r = lane & 31, h = lane >> 5, c = sc.c, N = sc.N, B = sc.B;
+    u32x4 oraw[NOR];
+    auto load_oraw = [&](int ntile) {   // 128 rows = 32*c pieces of 16 B, contiguous in memory
+        const int64_t row0 = (int64_t)ntile * 128;
+        const int valid = (int)max((int64_t)0, min((int64_t)128, (int64_t)N - row0)) * c;  // floats of real rows
+        const float *src = O + row0 * c;
+#pragma unroll
+        for (int i = 0; i < NOR; ++i) {
+            const int pc = i * 256 + ht;
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if (pc < 32 * c) {
+                if (4 * pc + 4 <= valid) x = *reinterpret_cast<const u32x4 *>(src + 4 * pc);
+                else
+                    for (int q = 0; q < 4; ++q)
+                        if (4 * pc + q < valid) x[q] = __builtin_bit_cast(unsigned, src[4 * pc + q]);
+            }
+            oraw[i] = x;
+        }
+    };
+    u32x4 sreg[NLD];
+    auto stage_load = [&](int mt) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(q_packed + (int64_t)mt * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ch = i * 256 + ht;
+            if (i + 1 < NLD || ch < CHUNKS) sreg[i] = src[ch];
+        }
+    };
+    auto stage_store = [&](int buf) {
+        u32x4 *dst = reinterpret_cast<u32x4 *>(stg + buf * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ch = i * 256 + ht;
+            if (i + 1 < NLD || ch < CHUNKS) dst[ch] = sreg[i];
+        }
+    };
+
+    if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    load_oraw((int)(sc.lin / sc.n_mt));
+    const unsigned ld4 = (unsigned)(ld_out * 4);
+    int ntile, mt0, cnt;
+    bool more;
+    while (sc.next(ntile, mt0, cnt, more)) {
+        const int j = ntile * 128 + w4 * 32 + r;     // entity: row of O, column of out
+#pragma unroll
+        for (int i = 0; i < NOR; ++i) {
+            const int pc = i * 256 + ht;
+            if (pc < 32 * c) reinterpret_cast<u32x4 *>(oreg)[pc] = oraw[i];
+        }
+        __syncthreads();                             // S1
+        stage_load(mt0);                             // first query tile of the sweep (the M waves are busy converting)
+        stage_store(0);
+        if (more) load_oraw(ntile + 1);              // stays in registers for the whole sweep
+        __syncthreads();                             // S2
+        if (STAMP && lane == 0 && g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
+        for (int i = 0; i < cnt + 2; ++i) {
+            const bool st = STAMP && i == 5 && lane == 0;
+            unsigned long long *sp = g_ws_stamps + (blockIdx.x * 8 + 4 + w4) * 8;
+            if (st) sp[0] = __builtin_amdgcn_s_memtime();
+            if (i >= 2 && !(XP & 2)) {               // scores of tile i-2: logistic + stores
+                const int mt = mt0 + i - 2;
+                const f32x4 *exr = reinterpret_cast<const f32x4 *>(oreg + (i & 1) * EX_BYTES + w4 * 4096);
+                const int rows = min(32, B - mt * 32);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    out + (int64_t)mt * 32 * ld_out, 0, (unsigned)(rows * ld_out * 4), 0x00020000);
+                // stage by stage over all 16 values: written element by element the compiler chains
+                // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
+                float zz[16], dd[16], pp[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 z = exr[g * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q];
+                }
+                if (SIGMOID == 2) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) zz[e] = fminf(zz[e] * -1.4426950408889634f, 126.0f);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dd[e] = 1.0f + __builtin_amdgcn_exp2f(zz[e]);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pp[e] = __builtin_amdgcn_rcpf(dd[e]);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pp[e] = fmaf(pp[e], fmaf(-dd[e], pp[e], 1.0f), pp[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
+                }
+                unsigned off = voff;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
+                    off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                }
+            }
+            if (st) sp[1] = sp[2] = sp[3] = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            if (st) sp[4] = __builtin_amdgcn_s_memtime();
+        }
+    }
+    if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+}
+
+template <int KS, int SIGMOID, bool STAMP = false, unsigned XP = 0>
+__global__ __launch_bounds__(512, 2) void score_ws_kernel(
+    const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
+    float *__restrict__ out, int64_t ld_out, bool o_vec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *const stg = lds;
+    unsigned char *const oreg = lds + 2 * tile_bytes<KS>();
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    Sched sc;
+    sc.B = B; sc.N = N; sc.c = c;
+    sc.n_mt = (B + 31) / 32;
+    const int64_t U = (int64_t)((N + 127) / 128) * sc.n_mt;
+    sc.lin = U * blockIdx.x / gridDim.x;
+    sc.lin_end = U * (blockIdx.x + 1) / gridDim.x;
+    // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) m_role<KS, STAMP, XP>(sc, q_packed, stg, oreg, o_vec, lane, wave & 3, t & 255);
+    else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, wave & 3, t & 255);
+}
+
+}  // namespace rtk_ws

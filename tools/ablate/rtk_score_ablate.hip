@@ -2,6 +2,7 @@
 // kernel source instantiated with compile-time ablation masks, to see where the time goes.
 // Build: tools/ablate/build.sh -> tools/ablate/librtk_ablate.so
 #include "rtk_score_split_kernel.h"
+#include "rtk_score_ws_kernel.h"
 
 void rtk_set_error(const char *, ...) {}
 
@@ -32,4 +33,32 @@ extern "C" int rtk_ablate_score_packed_f32(const void *qp, int64_t B, int c, con
     CASE(2, 64) CASE(2, 128) CASE(0, 128)
     CASE(0, 21) CASE(0, 22) CASE(2, 19) CASE(0, 53) CASE(2, 5) CASE(2, 37)
     return -5;
+}
+
+template <unsigned XP>
+static int ws_go(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld, int grid, void *stream) {
+    const size_t smem = rtk_ws::lds_bytes<13>(c);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<13, 2, true, XP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<13, 2, true, XP>), dim3(grid), dim3(512), smem, (hipStream_t)stream,
+                       (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld, c % 4 == 0);
+    return (int)hipGetLastError();
+}
+extern "C" int rtk_ablate_ws(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld,
+                             int grid, int xp, void *stream) {
+    if ((c + 15) / 16 != 13) return -3;
+    switch (xp) {
+        case 0: return ws_go<0>(qp, B, c, O, N, out, ld, grid, stream);
+        case 1: return ws_go<1>(qp, B, c, O, N, out, ld, grid, stream);
+        case 2: return ws_go<2>(qp, B, c, O, N, out, ld, grid, stream);
+        case 3: return ws_go<3>(qp, B, c, O, N, out, ld, grid, stream);
+    }
+    return -5;
+}
+extern "C" int rtk_ablate_ws_stamps(unsigned long long *host, int n, int clear) {
+    if (clear) {
+        static unsigned long long zeros[256 * 64];
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(rtk_ws::g_ws_stamps), zeros, sizeof(zeros));
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rtk_ws::g_ws_stamps), sizeof(unsigned long long) * n);
 }
