@@ -174,6 +174,14 @@ def main():
     # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
     alg_bytes = n_loc * c * 4 + B * n_loc * 4 + B * c * 4
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if they match
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tj = json.load(f)
+        if tj["workload"] == args.workload and world == 1 and not args.exact:
+            traffic = tj["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     result = {
         "metric": "1-vs-N triples scored/sec", "value": args.steps * B / dt, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -185,8 +193,8 @@ def main():
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
         "scores_per_s": args.steps * B * n_ent / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "score_split_kernel" if not args.exact else "gemm_f32_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "score_ws_kernel" if not args.exact else "gemm_f32_kernel",
                      "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
     }
     if world > 1:
