@@ -116,6 +116,32 @@ int rtk_score_1vN_f32(const float *core, int a, int b, int c,
                       void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * bf16 operand path (BASELINE.json configs[2], [4]): core, R, S, O are bf16 (raw 16-bit
+ * storage, torch.bfloat16), all accumulation is fp32, the query vectors are rounded to bf16
+ * before the score product (v_mfma_f32_32x32x16_bf16), scores are fp32.  Same argument
+ * meaning, workspace rules (query sizes with dtype = RTK_BF16) and reference lines as the
+ * _f32 entry points above.
+ */
+int rtk_query_vectors_bf16(const void *core, int a, int b, int c,
+                           const void *R, int64_t n_rel,
+                           const void *S, int64_t n_sub,
+                           const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                           float *v_out, void *q_packed,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
+                          const void *O, int64_t n_local,
+                          float *out, int64_t ld_out, unsigned flags, void *stream);
+
+int rtk_score_1vN_bf16(const void *core, int a, int b, int c,
+                       const void *R, int64_t n_rel,
+                       const void *S, int64_t n_sub,
+                       const void *O, int64_t n_local,
+                       const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                       float *out, int64_t ld_out, unsigned flags,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * General fp32 MFMA GEMM used by the backward pass and as the exact fallback:
  *   C[m,n] (+)= sum_k A(m,k) * B(n,k)
  * A(m,k) = A[m*lda + k] if a_kmajor else A[k*lda + m]; likewise B(n,k).

@@ -32,6 +32,9 @@ SIGNATURES = {
     "rtk_score_f32": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _u, _p]),
     "rtk_score_packed_f32": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _u, _p]),
     "rtk_score_1vN_f32": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _u, _p, _sz, _p]),
+    "rtk_query_vectors_bf16": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "rtk_score_packed_bf16": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _u, _p]),
+    "rtk_score_1vN_bf16": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _u, _p, _sz, _p]),
     "rtk_gemm_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _u, _p]),
 }
 

@@ -22,6 +22,10 @@ int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const flo
                                const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
                                const RtkWorkspace &ws, hipStream_t st);
 int rtk_split_ksteps_supported(int c);
+int rtk_query_vectors_bf16_impl(const void *core, int a, int b, int c, const void *R, int64_t n_rel,
+                                const void *S, int64_t n_sub, const int64_t *rel_idx,
+                                const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
+                                const RtkWorkspace &ws, hipStream_t st);
 
 static size_t packed_bytes(int dtype, int64_t batch, int c) {
     const int ks = (c + 15) / 16;
@@ -120,4 +124,35 @@ extern "C" int rtk_score_1vN_f32(const float *core, int a, int b, int c, const f
     if (exact) return rtk_score_f32(ws.v, batch, c, O, n_local, out, ld_out, flags & RTK_SCORE_SIGMOID, stream);
     return rtk_score_packed_f32(ws.q_packed, batch, c, O, n_local, out, ld_out,
                                 flags & (RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST), stream);
+}
+
+extern "C" int rtk_query_vectors_bf16(const void *core, int a, int b, int c, const void *R, int64_t n_rel,
+                                      const void *S, int64_t n_sub, const int64_t *rel_idx,
+                                      const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_common("rtk_query_vectors_bf16", core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch,
+                          workspace, workspace_bytes, RTK_BF16);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(v_out || q_packed, RTK_ERR_BAD_ARG, "rtk_query_vectors_bf16: both outputs are NULL");
+    RtkWorkspace ws = carve(workspace, RTK_BF16, batch, n_rel, a, b, c);
+    return rtk_query_vectors_bf16_impl(core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch, v_out,
+                                       q_packed, ws, (hipStream_t)stream);
+}
+
+extern "C" int rtk_score_1vN_bf16(const void *core, int a, int b, int c, const void *R, int64_t n_rel,
+                                  const void *S, int64_t n_sub, const void *O, int64_t n_local,
+                                  const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *out,
+                                  int64_t ld_out, unsigned flags, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
+    int rc = check_common("rtk_score_1vN_bf16", core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch,
+                          workspace, workspace_bytes, RTK_BF16);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(O && out && n_local > 0 && ld_out >= n_local, RTK_ERR_BAD_ARG, "rtk_score_1vN_bf16: bad O/out/n_local/ld_out");
+    RTK_REQUIRE(c <= 512, RTK_ERR_UNSUPPORTED, "rtk_score_1vN_bf16: c=%d > 512 not supported", c);
+    RtkWorkspace ws = carve(workspace, RTK_BF16, batch, n_rel, a, b, c);
+    rc = rtk_query_vectors_bf16_impl(core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch, nullptr,
+                                     ws.q_packed, ws, (hipStream_t)stream);
+    if (rc != RTK_OK) return rc;
+    return rtk_score_packed_bf16(ws.q_packed, batch, c, O, n_local, out, ld_out,
+                                 flags & (RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST), stream);
 }

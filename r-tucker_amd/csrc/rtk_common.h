@@ -51,6 +51,27 @@ struct RtkWorkspace {
 
 // device side -------------------------------------------------------------
 #ifdef __HIPCC__
+// Operand element types: float, or bf16 carried as its raw 16 bits (torch.bfloat16 storage).
+typedef unsigned short rtk_bf16;
+__device__ __forceinline__ float rtk_to_f32(float x) { return x; }
+__device__ __forceinline__ float rtk_to_f32(rtk_bf16 x) { return __builtin_bit_cast(float, (unsigned)x << 16); }
+// round-to-nearest-even fp32 -> bf16 bits (NaN stays NaN: plain cast semantics of v_cvt_pk_bf16_f32)
+__device__ __forceinline__ rtk_bf16 rtk_f32_to_bf16(float x) {
+    return __builtin_bit_cast(rtk_bf16, (__bf16)x);
+}
+// 4 consecutive elements -> f32x4 (p must be 16-B aligned for float, 8-B aligned for bf16)
+__device__ __forceinline__ f32x4 rtk_load4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x4 rtk_load4(const rtk_bf16 *p) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 w = *reinterpret_cast<const u32x2 *>(p);
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, w[0] << 16);
+    r[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, w[1] << 16);
+    r[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+    return r;
+}
+template <typename T> __host__ __device__ constexpr int rtk_vec4_align() { return sizeof(T) == 4 ? 16 : 8; }
 // Correctly behaving fp32 logistic: 1/(1+exp(-x)) with ocml expf (<= 1 ulp) and an
 // IEEE division, the same formula torch's CPU kernel evaluates; saturates to
 // exactly 1.0f for x >~ 16.64 like the reference.

@@ -27,7 +27,8 @@ struct Stage8 {
 
 // K-major operand: element (row, k) at base[row*ld + k].  Thread t owns row
 // (t & 127) of the tile and k in [kh, kh+8), kh = 8*(t >> 7).
-__device__ __forceinline__ void load_kmajor(Stage8 &s, const float *__restrict__ base, int64_t ld,
+template <typename T>
+__device__ __forceinline__ void load_kmajor(Stage8 &s, const T *__restrict__ base, int64_t ld,
                                             const int32_t *__restrict__ rows, int row0, int nrows,
                                             int k0, int K, int t, bool vec_ok) {
     const int r = row0 + (t & 127);
@@ -36,10 +37,10 @@ __device__ __forceinline__ void load_kmajor(Stage8 &s, const float *__restrict__
     for (int j = 0; j < 8; ++j) s.v[j] = 0.f;
     if (r >= nrows) return;
     const int64_t rr = rows ? (int64_t)rows[r] : (int64_t)r;
-    const float *p = base + rr * ld + k;
+    const T *p = base + rr * ld + k;
     if (vec_ok && k + 8 <= K) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(p);
-        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(p + 4);
+        const f32x4 x0 = rtk_load4(p);
+        const f32x4 x1 = rtk_load4(p + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s.v[j] = x0[j];
@@ -48,7 +49,7 @@ __device__ __forceinline__ void load_kmajor(Stage8 &s, const float *__restrict__
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (k + j < K) s.v[j] = p[j];
+            if (k + j < K) s.v[j] = rtk_to_f32(p[j]);
     }
 }
 __device__ __forceinline__ void store_kmajor(const Stage8 &s, float *__restrict__ tile, int t) {
@@ -59,17 +60,18 @@ __device__ __forceinline__ void store_kmajor(const Stage8 &s, float *__restrict_
 
 // M-major operand: element (row, k) at base[k*ld + row].  Thread t owns k = t >> 4
 // and rows [m8, m8+8), m8 = 8*(t & 15).
-__device__ __forceinline__ void load_mmajor(Stage8 &s, const float *__restrict__ base, int64_t ld,
+template <typename T>
+__device__ __forceinline__ void load_mmajor(Stage8 &s, const T *__restrict__ base, int64_t ld,
                                             int row0, int nrows, int k0, int K, int t, bool vec_ok) {
     const int k = k0 + (t >> 4);
     const int r = row0 + 8 * (t & 15);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s.v[j] = 0.f;
     if (k >= K) return;
-    const float *p = base + (int64_t)k * ld + r;
+    const T *p = base + (int64_t)k * ld + r;
     if (vec_ok && r + 8 <= nrows) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(p);
-        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(p + 4);
+        const f32x4 x0 = rtk_load4(p);
+        const f32x4 x1 = rtk_load4(p + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s.v[j] = x0[j];
@@ -78,7 +80,7 @@ __device__ __forceinline__ void load_mmajor(Stage8 &s, const float *__restrict__
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (r + j < nrows) s.v[j] = p[j];
+            if (r + j < nrows) s.v[j] = rtk_to_f32(p[j]);
     }
 }
 __device__ __forceinline__ void store_mmajor(const Stage8 &s, float *__restrict__ tile, int t) {
@@ -93,10 +95,10 @@ __device__ __forceinline__ void store_mmajor(const Stage8 &s, float *__restrict_
     *reinterpret_cast<f32x4 *>(&tile[k * LDT + m8 + 4]) = x1;
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool SIGMOID>
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, bool SIGMOID>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
-    const float *__restrict__ A, int64_t lda, const int32_t *__restrict__ a_rows, bool a_vec,
-    const float *__restrict__ B, int64_t ldb, bool b_vec,
+    const T *__restrict__ A, int64_t lda, const int32_t *__restrict__ a_rows, bool a_vec,
+    const T *__restrict__ B, int64_t ldb, bool b_vec,
     float *__restrict__ C, int64_t ldc, int M, int N, int K,
     const uint32_t *__restrict__ m_dev) {
     __shared__ __attribute__((aligned(16))) float As[BK * LDT];
@@ -174,12 +176,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         }
 }
 
-template <bool AK, bool BK_, bool SG>
-void launch(const float *A, int64_t lda, const int32_t *a_rows, bool a_vec, const float *B, int64_t ldb,
+template <typename T, bool AK, bool BK_, bool SG>
+void launch(const T *A, int64_t lda, const int32_t *a_rows, bool a_vec, const T *B, int64_t ldb,
             bool b_vec, float *C, int64_t ldc, int M, int N, int K, const uint32_t *m_dev,
             hipStream_t st) {
     dim3 grid((unsigned)rtk_cdiv(N, BN), (unsigned)rtk_cdiv(M, BM));
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, SG>), grid, dim3(256), 0, st, A, lda, a_rows, a_vec, B,
+    hipLaunchKernelGGL((gemm_f32_kernel<T, AK, BK_, SG>), grid, dim3(256), 0, st, A, lda, a_rows, a_vec, B,
                        ldb, b_vec, C, ldc, M, N, K, m_dev);
 }
 
@@ -189,26 +191,17 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Internal entry (also used by the query-vector stage for large relation rank):
 // optional row gather on A (K-major only) and a device-side row count.
-int rtk_gemm_f32_ex(const float *A, int a_kmajor, int64_t lda, const int32_t *a_rows,
-                    const float *B, int b_kmajor, int64_t ldb, float *C, int64_t ldc,
-                    int64_t M, int64_t N, int64_t K, unsigned flags, const uint32_t *m_dev,
-                    hipStream_t st) {
-    RTK_REQUIRE(A && B && C, RTK_ERR_BAD_ARG, "rtk_gemm_f32: null operand");
-    RTK_REQUIRE(M > 0 && N > 0 && K > 0, RTK_ERR_BAD_ARG, "rtk_gemm_f32: sizes must be positive (M=%lld N=%lld K=%lld)",
-                (long long)M, (long long)N, (long long)K);
-    RTK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), RTK_ERR_UNSUPPORTED,
-                "rtk_gemm_f32: dimension exceeds 2^31-1");
-    RTK_REQUIRE(rtk_cdiv(M, BM) <= 65535, RTK_ERR_UNSUPPORTED, "rtk_gemm_f32: M too large for grid.y");
-    RTK_REQUIRE(!(a_rows && !a_kmajor), RTK_ERR_BAD_ARG, "rtk_gemm_f32: row gather needs a K-major A");
-    RTK_REQUIRE(ldc >= N, RTK_ERR_BAD_ARG, "rtk_gemm_f32: ldc < N");
-    const bool a_vec = aligned16(A) && (lda % 4 == 0);
-    const bool b_vec = aligned16(B) && (ldb % 4 == 0);
-    const bool sg = (flags & RTK_SCORE_SIGMOID) != 0;
-    const int m = (int)M, n = (int)N, k = (int)K;
-#define RTK_GO(AK, BK_)                                                                              \
-    do {                                                                                             \
-        if (sg) launch<AK, BK_, true>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st); \
-        else launch<AK, BK_, false>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st);  \
+template <typename T>
+static int gemm_dispatch(const T *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const T *B, int b_kmajor,
+                         int64_t ldb, float *C, int64_t ldc, int m, int n, int k, bool sg, const uint32_t *m_dev,
+                         hipStream_t st) {
+    constexpr uintptr_t VA = rtk_vec4_align<T>();
+    const bool a_vec = ((reinterpret_cast<uintptr_t>(A) & (VA - 1)) == 0) && (lda % 4 == 0);
+    const bool b_vec = ((reinterpret_cast<uintptr_t>(B) & (VA - 1)) == 0) && (ldb % 4 == 0);
+#define RTK_GO(AK, BK_)                                                                                        \
+    do {                                                                                                       \
+        if (sg) launch<T, AK, BK_, true>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st);    \
+        else launch<T, AK, BK_, false>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st);      \
     } while (0)
     if (a_kmajor && b_kmajor) RTK_GO(true, true);
     else if (a_kmajor && !b_kmajor) RTK_GO(true, false);
@@ -218,10 +211,32 @@ int rtk_gemm_f32_ex(const float *A, int a_kmajor, int64_t lda, const int32_t *a_
     return rtk_check_launch("rtk_gemm_f32");
 }
 
+// Internal entry (also used by the query-vector stage for large relation rank):
+// optional row gather on A (K-major only), a device-side row count, bf16 operands.
+int rtk_gemm_f32_ex(const void *A, int a_kmajor, int64_t lda, const int32_t *a_rows,
+                    const void *B, int b_kmajor, int64_t ldb, float *C, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, unsigned flags, const uint32_t *m_dev, int in_bf16,
+                    hipStream_t st) {
+    RTK_REQUIRE(A && B && C, RTK_ERR_BAD_ARG, "rtk_gemm_f32: null operand");
+    RTK_REQUIRE(M > 0 && N > 0 && K > 0, RTK_ERR_BAD_ARG, "rtk_gemm_f32: sizes must be positive (M=%lld N=%lld K=%lld)",
+                (long long)M, (long long)N, (long long)K);
+    RTK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), RTK_ERR_UNSUPPORTED,
+                "rtk_gemm_f32: dimension exceeds 2^31-1");
+    RTK_REQUIRE(rtk_cdiv(M, BM) <= 65535, RTK_ERR_UNSUPPORTED, "rtk_gemm_f32: M too large for grid.y");
+    RTK_REQUIRE(!(a_rows && !a_kmajor), RTK_ERR_BAD_ARG, "rtk_gemm_f32: row gather needs a K-major A");
+    RTK_REQUIRE(ldc >= N, RTK_ERR_BAD_ARG, "rtk_gemm_f32: ldc < N");
+    const bool sg = (flags & RTK_SCORE_SIGMOID) != 0;
+    if (in_bf16)
+        return gemm_dispatch<rtk_bf16>((const rtk_bf16 *)A, a_kmajor, lda, a_rows, (const rtk_bf16 *)B, b_kmajor, ldb, C,
+                                       ldc, (int)M, (int)N, (int)K, sg, m_dev, st);
+    return gemm_dispatch<float>((const float *)A, a_kmajor, lda, a_rows, (const float *)B, b_kmajor, ldb, C, ldc,
+                                (int)M, (int)N, (int)K, sg, m_dev, st);
+}
+
 extern "C" int rtk_gemm_f32(const float *A, int a_kmajor, int64_t lda, const float *B, int b_kmajor,
                             int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                             unsigned flags, void *stream) {
-    return rtk_gemm_f32_ex(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, C, ldc, M, N, K, flags, nullptr,
+    return rtk_gemm_f32_ex(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, C, ldc, M, N, K, flags, nullptr, 0,
                            (hipStream_t)stream);
 }
 
@@ -229,5 +244,5 @@ extern "C" int rtk_score_f32(const float *v, int64_t batch, int c, const float *
                              float *out, int64_t ld_out, unsigned flags, void *stream) {
     RTK_REQUIRE(c > 0, RTK_ERR_BAD_ARG, "rtk_score_f32: c must be positive");
     return rtk_gemm_f32_ex(v, 1, c, nullptr, O, 1, c, out, ld_out, batch, n_local, c,
-                           flags & RTK_SCORE_SIGMOID, nullptr, (hipStream_t)stream);
+                           flags & RTK_SCORE_SIGMOID, nullptr, 0, (hipStream_t)stream);
 }

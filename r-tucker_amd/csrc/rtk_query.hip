@@ -50,9 +50,9 @@ __global__ __launch_bounds__(1024) void plan_kernel(const int64_t *__restrict__ 
 // small relation rank (a <= 32: WN18RR has a = 10): each thread owns one float4 of
 // n for UT relations, so every G element is loaded once per UT relations.
 constexpr int UT = 4;
-template <bool VEC>
-__global__ __launch_bounds__(256) void tables_kernel(const float *__restrict__ G, int a, int64_t bc,
-                                                     const float *__restrict__ R,
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, int a, int64_t bc,
+                                                     const T *__restrict__ R,
                                                      const int32_t *__restrict__ rel_list, int n_u_max,
                                                      const uint32_t *__restrict__ n_u_dev,
                                                      float *__restrict__ M) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void tables_kernel(const float *__restrict__ G
         float x = 0.f;
         if (u < n_u) {
             const int rel = rel_list ? rel_list[u] : u;
-            x = R[(int64_t)rel * a + ai];
+            x = rtk_to_f32(R[(int64_t)rel * a + ai]);
         }
         Rs[(i / a) * 64 + ai] = x;
     }
@@ -87,11 +87,11 @@ __global__ __launch_bounds__(256) void tables_kernel(const float *__restrict__ G
         for (int k = 0; k < 8; ++k) {
             const int ai = min(a0 + k, a - 1);
             if (VEC) {
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(G + (int64_t)ai * bc + n);
+                const f32x4 x = rtk_load4(G + (int64_t)ai * bc + n);
 #pragma unroll
                 for (int j = 0; j < W; ++j) g[k][j] = x[j];
             } else {
-                g[k][0] = G[(int64_t)ai * bc + n];
+                g[k][0] = rtk_to_f32(G[(int64_t)ai * bc + n]);
             }
         }
 #pragma unroll
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256) void tables_kernel(const float *__restrict__ G
 // One workgroup per query d:  v_d[c] = sum_b S[h_d, b] * M_slot[b, c].
 // 256 threads = G groups x (c/W) column slots; group g takes b = g, g+G, ...;
 // partial sums meet in LDS.  The finished row is written as fp32 and/or packed.
-template <bool VEC>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__ M, int b, int c,
-                                                       const float *__restrict__ S, int64_t n_sub,
+                                                       const T *__restrict__ S, int64_t n_sub,
                                                        const int64_t *__restrict__ rel_idx,
                                                        const int64_t *__restrict__ sub_idx, int n_rel,
                                                        const int32_t *__restrict__ slot_of_rel,
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
     const int slot = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
     const float *Mq = M + (int64_t)slot * b * c;
 
-    for (int i = t; i < b; i += 256) s_row[i] = S[h * b + i];
+    for (int i = t; i < b; i += 256) s_row[i] = rtk_to_f32(S[h * b + i]);
     __syncthreads();
 
     for (int pass = 0; pass < npass; ++pass) {
@@ -192,6 +192,15 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
         if (v_out) v_out[(int64_t)d * c + k] = x;
     }
     if (!q_packed) return;
+    if (sizeof(T) == 2) {
+        // bf16 path: one plane of bf16 (round to nearest even), no scaling (bf16 has fp32's range)
+        unsigned char *tile = q_packed + (int64_t)(d >> 5) * rtk_pack_tile_bytes(ksteps, 1);
+        const int row = d & 31;
+        if (t == 0) reinterpret_cast<float *>(tile)[row] = 1.0f;
+        rtk_bf16 *plane = reinterpret_cast<rtk_bf16 *>(tile + RTK_PACK_HDR);
+        for (int k = t; k < ksteps * 16; k += 256) plane[rtk_pack_offset(ksteps, k, row)] = rtk_f32_to_bf16((k < c) ? part[k] : 0.f);
+        return;
+    }
     // row maximum -> power-of-two scale
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -216,15 +225,16 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
 
 }  // namespace
 
-int rtk_gemm_f32_ex(const float *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const float *B,
+int rtk_gemm_f32_ex(const void *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const void *B,
                     int b_kmajor, int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                    unsigned flags, const uint32_t *m_dev, hipStream_t st);
+                    unsigned flags, const uint32_t *m_dev, int in_bf16, hipStream_t st);
 
-// Enqueue stage 1.  `ws` already carved (rtk_abi.hip).
-int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
-                               const float *S, int64_t n_sub, const int64_t *rel_idx,
-                               const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
-                               const RtkWorkspace &ws, hipStream_t st) {
+// Enqueue stage 1.  `ws` already carved (rtk_abi.hip).  T = float or rtk_bf16 (operands);
+// tables, accumulation and v_out are fp32 either way.
+template <typename T>
+static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, int64_t n_rel, const T *S,
+                              int64_t n_sub, const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                              float *v_out, void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
     const int64_t bc = (int64_t)b * c;
     const bool planned = n_rel > batch;  // otherwise: one table per relation id, slot == id
     const int n_u_max = (int)(planned ? batch : n_rel);
@@ -236,15 +246,17 @@ int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const flo
     }
     const int32_t *rel_list = planned ? ws.rel_list : nullptr;
     const uint32_t *n_u_dev = planned ? ws.flags + 1 : nullptr;
+    constexpr int VA = rtk_vec4_align<T>();
     if (a <= 32) {
-        const bool vec = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(core) & 15) == 0);
+        const bool vec = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(core) & (VA - 1)) == 0);
         const int W = vec ? 4 : 1;
         dim3 grid((unsigned)rtk_cdiv(bc, 256 * W), (unsigned)rtk_cdiv(n_u_max, UT));
-        if (vec) hipLaunchKernelGGL(tables_kernel<true>, grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
-        else hipLaunchKernelGGL(tables_kernel<false>, grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
+        if (vec) hipLaunchKernelGGL((tables_kernel<T, true>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
+        else hipLaunchKernelGGL((tables_kernel<T, false>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
     } else {
-        // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM
-        int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, ws.tables, bc, n_u_max, bc, a, 0, n_u_dev, st);
+        // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM (bf16 operands widen on load)
+        int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, ws.tables, bc, n_u_max, bc, a, 0, n_u_dev,
+                                 sizeof(T) == 2, st);
         if (rc != RTK_OK) return rc;
     }
     const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws.tables) & 15) == 0);
@@ -254,7 +266,22 @@ int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const flo
     const size_t smem = (size_t)(((b + 3) & ~3) + (size_t)ngroups * cols * W) * sizeof(float);
     RTK_REQUIRE(smem <= 64 * 1024, RTK_ERR_UNSUPPORTED, "rtk_query_vectors: rank too large for the contract kernel (b=%d c=%d)", b, c);
     const int ksteps = (c + 15) / 16;
-    if (vec) hipLaunchKernelGGL(contract_kernel<true>, dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
-    else hipLaunchKernelGGL(contract_kernel<false>, dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
-    return rtk_check_launch("rtk_query_vectors_f32");
+    if (vec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
+    else hipLaunchKernelGGL((contract_kernel<T, false>), dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
+    return rtk_check_launch("rtk_query_vectors");
+}
+
+int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
+                               const float *S, int64_t n_sub, const int64_t *rel_idx,
+                               const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
+                               const RtkWorkspace &ws, hipStream_t st) {
+    return query_vectors_impl<float>(core, a, b, c, R, n_rel, S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed, ws, st);
+}
+
+int rtk_query_vectors_bf16_impl(const void *core, int a, int b, int c, const void *R, int64_t n_rel,
+                                const void *S, int64_t n_sub, const int64_t *rel_idx,
+                                const int64_t *sub_idx, int64_t batch, float *v_out, void *q_packed,
+                                const RtkWorkspace &ws, hipStream_t st) {
+    return query_vectors_impl<rtk_bf16>((const rtk_bf16 *)core, a, b, c, (const rtk_bf16 *)R, n_rel,
+                                        (const rtk_bf16 *)S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed, ws, st);
 }

@@ -1,0 +1,207 @@
+// Stage 2 for bf16 operands:  out[d, j] = logistic( v[d,:] . O[j,:] ),  v and O in bf16,
+// fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 scores.   (reference: R_TuckER.py:47-48
+// with bf16 parameters -- BASELINE.json configs[2], FB15k-237 symmetric rank (200,200) B 2048.)
+//
+// Same "entity-stationary" skeleton as the split-fp16 kernel (rtk_score_split_kernel.h) with one
+// operand plane and no scaling: a wave keeps the bf16 B fragments of its 32 entity rows in
+// registers (loaded straight from O: a fragment IS 16 contiguous bytes of a row), the workgroup
+// sweeps 32-query tiles of the packed bf16 plane through a register-staged, double-buffered LDS
+// tile, KS MFMAs per tile on two alternating accumulators, logistic + branch-free buffer stores
+// of the previous tile in the MFMA gaps.  With a third of the MFMA work of the fp32 path the
+// kernel is bound by the fp32 score write (HBM).
+#include "rtk_common.h"
+#include "rtk_pack.h"
+
+namespace {
+
+__device__ __forceinline__ float logistic_fast(float z) {
+    const float t = fminf(z * -1.4426950408889634f, 126.0f);
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float d = 1.0f + e;
+    const float p = __builtin_amdgcn_rcpf(d);
+    return fmaf(p, fmaf(-d, p, 1.0f), p);
+}
+
+template <int KS, int SIGMOID, int MINW>
+__global__ __launch_bounds__(256, MINW) void score_bf16_kernel(
+    const unsigned char *__restrict__ q_packed, int B, const rtk_bf16 *__restrict__ O, int N, int c,
+    float *__restrict__ out, int64_t ld_out, bool o_vec) {
+    constexpr int TILE_BYTES = RTK_PACK_HDR + KS * 1024;
+    constexpr int CHUNKS = TILE_BYTES / 16;
+    constexpr int NLD = (CHUNKS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * TILE_BYTES
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_mt = (B + 31) / 32;
+    const int64_t U = (int64_t)((N + 127) / 128) * n_mt;
+    int64_t lin = U * blockIdx.x / gridDim.x;
+    const int64_t lin_end = U * (blockIdx.x + 1) / gridDim.x;
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(q_packed), 0, (unsigned)(n_mt * TILE_BYTES), 0x00020000);
+
+    while (lin < lin_end) {
+        const int ntile = (int)(lin / n_mt), mt0 = (int)(lin % n_mt);
+        const int cnt = (int)min((int64_t)(n_mt - mt0), lin_end - lin);
+        lin += cnt;
+        const int j = ntile * 128 + wave * 32 + r;  // entity (row of O, column of out)
+
+        // B fragments: lane (r, h) holds k = 16*ks + 8*h + q, q < 8 of row j = 16 contiguous bytes
+        const rtk_bf16 *orow = O + (int64_t)min(j, N - 1) * c;
+        bf16x8 Bf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 16 * ks + 8 * h;
+            bf16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (o_vec) {  // c % 8 == 0: a fragment is wholly inside or wholly outside the row
+                if (k + 8 <= c) x = *reinterpret_cast<const bf16x8 *>(orow + k);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k + q < c) x[q] = (short)orow[k + q];
+            }
+            Bf[ks] = x;
+        }
+
+        u32x4 stg[NLD];
+        auto stage_load = [&](int mt) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const unsigned vo = (i + 1 < NLD || i * 256 + t < CHUNKS) ? (unsigned)(t * 16) : 0x80000000u;
+                stg[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, mt * TILE_BYTES + i * 4096, 0);
+            }
+        };
+        auto stage_store = [&](int buf) {
+            u32x4 *dst = reinterpret_cast<u32x4 *>(lds + buf * TILE_BYTES);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int ch = i * 256 + t;
+                if (i + 1 < NLD || ch < CHUNKS) dst[ch] = stg[i];
+            }
+        };
+        const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
+        const unsigned ld4 = (unsigned)(ld_out * 4);
+        __amdgpu_buffer_rsrc_t ers;
+        unsigned ep_off = voff;
+        auto epilogue_begin = [&](int mt, bool live) {
+            const int rows = live ? min(32, B - mt * 32) : 0;
+            ers = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)max(mt, 0) * 32 * ld_out, 0,
+                                                    (unsigned)(rows * ld_out * 4), 0x00020000);
+            ep_off = voff;
+            asm volatile("" : "+v"(ep_off));
+        };
+        float ep_d = 1.f, ep_p = 1.f;
+        auto piece = [&](const f32x16 &z, int pc) {   // 32 pieces: 16 values x {exp half, reciprocal half + store}
+            const int e = pc >> 1;
+            if ((pc & 1) == 0) {
+                if (SIGMOID == 2) {
+                    const float tt = fminf(z[e] * -1.4426950408889634f, 126.0f);
+                    ep_d = 1.0f + __builtin_amdgcn_exp2f(tt);
+                    ep_p = __builtin_amdgcn_rcpf(ep_d);
+                } else if (SIGMOID == 1) {
+                    ep_d = 1.0f + expf(-z[e]);
+                } else {
+                    ep_p = z[e];
+                }
+            } else {
+                float pv = ep_p;
+                if (SIGMOID == 2) pv = fmaf(ep_p, fmaf(-ep_d, ep_p, 1.0f), ep_p);
+                if (SIGMOID == 1) pv = 1.0f / ep_d;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, 0);
+                ep_off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+            }
+        };
+
+        __syncthreads();   // previous unit's last tile fully read before restaging buffer 0
+        stage_load(mt0);
+        stage_store(0);
+        __syncthreads();
+        f32x16 prev;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) prev[e] = 0.f;
+        for (int i = 0; i < cnt; ++i) {
+            const int cur = i & 1;
+            if (i + 1 < cnt) stage_load(mt0 + i + 1);
+            const bf16x8 *la = reinterpret_cast<const bf16x8 *>(lds + cur * TILE_BYTES + RTK_PACK_HDR);
+            f32x16 acc, acc2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = acc2[e] = 0.f;
+            epilogue_begin(mt0 + i - 1, i > 0);
+            constexpr int PF = KS < 3 ? KS : 3;
+            bf16x8 fa[PF];
+#pragma unroll
+            for (int p = 0; p < PF; ++p) fa[p] = la[p * 64 + lane];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = fa[ks % PF];
+                if (ks + PF < KS) fa[ks % PF] = la[(ks + PF) * 64 + lane];
+                if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bf[ks], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bf[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int pc = ks * 32 / KS; pc < (ks + 1) * 32 / KS; ++pc) piece(prev, pc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) prev[e] = acc[e] + acc2[e];
+            stage_store(cur ^ 1);   // unconditional: a stale tile in the spare buffer is never read
+            __syncthreads();
+        }
+        epilogue_begin(mt0 + cnt - 1, true);
+#pragma unroll
+        for (int pc = 0; pc < 32; ++pc) piece(prev, pc);
+    }
+}
+
+template <int KS, int SG, int MINW>
+void launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
+                hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)(RTK_PACK_HDR + KS * 1024);
+    static bool attr_set = false;
+    if (smem > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const int64_t units = rtk_cdiv(N, 128) * rtk_cdiv(B, 32);
+    const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
+    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW>), dim3(grid), dim3(256), smem, st, qp, B, O, N, c, out, ld, o_vec);
+}
+
+template <int KS, int MINW>
+void launch_ks(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, int sg,
+               bool o_vec, hipStream_t st) {
+    if (sg == 0) launch_one<KS, 0, MINW>(qp, B, O, N, c, out, ld, o_vec, st);
+    else if (sg == 1) launch_one<KS, 1, MINW>(qp, B, O, N, c, out, ld, o_vec, st);
+    else launch_one<KS, 2, MINW>(qp, B, O, N, c, out, ld, o_vec, st);
+}
+
+}  // namespace
+
+extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c, const void *O, int64_t n_local,
+                                     float *out, int64_t ld_out, unsigned flags, void *stream) {
+    RTK_REQUIRE(q_packed && O && out, RTK_ERR_BAD_ARG, "rtk_score_packed_bf16: null operand");
+    RTK_REQUIRE(batch > 0 && n_local > 0 && c > 0, RTK_ERR_BAD_ARG, "rtk_score_packed_bf16: sizes must be positive");
+    RTK_REQUIRE(ld_out >= n_local, RTK_ERR_BAD_ARG, "rtk_score_packed_bf16: ld_out < n_local");
+    RTK_REQUIRE(ld_out < (1ll << 24), RTK_ERR_UNSUPPORTED, "rtk_score_packed_bf16: ld_out >= 2^24");
+    RTK_REQUIRE(batch < (1ll << 31) && n_local < (1ll << 31) - 256, RTK_ERR_UNSUPPORTED, "rtk_score_packed_bf16: dimension too large");
+    RTK_REQUIRE(c <= 512, RTK_ERR_UNSUPPORTED, "rtk_score_packed_bf16: c=%d > 512 not supported", c);
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = (c + 15) / 16;
+    const int sg = !(flags & RTK_SCORE_SIGMOID) ? 0 : ((flags & RTK_SCORE_SIGMOID_FAST) ? 2 : 1);
+    const bool o_vec = (c % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
+    const unsigned char *qp = (const unsigned char *)q_packed;
+    const rtk_bf16 *Ob = (const rtk_bf16 *)O;
+    const int B = (int)batch, N = (int)n_local;
+#define RTK_KS(K_, W_) case K_: launch_ks<K_, W_>(qp, B, Ob, N, c, out, ld_out, sg, o_vec, st); break;
+    switch (ks) {
+        RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
+        RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)
+        RTK_KS(17, 2) RTK_KS(18, 2) RTK_KS(19, 2) RTK_KS(20, 2) RTK_KS(21, 2) RTK_KS(22, 2) RTK_KS(23, 2) RTK_KS(24, 2)
+        RTK_KS(25, 2) RTK_KS(26, 2) RTK_KS(27, 2) RTK_KS(28, 2) RTK_KS(29, 2) RTK_KS(30, 2) RTK_KS(31, 2) RTK_KS(32, 2)
+        default:
+            rtk_set_error("rtk_score_packed_bf16: unsupported k-step count %d", ks);
+            return RTK_ERR_UNSUPPORTED;
+    }
+#undef RTK_KS
+    return rtk_check_launch("rtk_score_packed_bf16");
+}

@@ -33,11 +33,16 @@ def _require_gpu(name, t):
             "use the reference implementation or oracle/ for CPU runs)")
 
 
-def _f32c(name, t):
+def _operand(name, t, dtype):
     _require_gpu(name, t)
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"{name} must be float32 for the fp32 path, got {t.dtype}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} is {t.dtype} but the core is {dtype}: all operands must share one dtype "
+                           "(float32, or bfloat16 for the bf16 path)")
     return t.contiguous()
+
+
+def _f32c(name, t):
+    return _operand(name, t, torch.float32)
 
 
 def _idx(name, t, device):
@@ -64,7 +69,12 @@ def _stream_ptr(device):
 
 def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None, out=None):
     lib = _lib.load()
-    core, R, S, O = _f32c("core", core), _f32c("R", R), _f32c("S", S), _f32c("O", O)
+    _require_gpu("core", core)
+    if core.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"core must be float32 or bfloat16, got {core.dtype}")
+    bf16 = core.dtype == torch.bfloat16
+    dt = core.dtype
+    core, R, S, O = _operand("core", core, dt), _operand("R", R, dt), _operand("S", S, dt), _operand("O", O, dt)
     dev = core.device
     for n, t in (("R", R), ("S", S), ("O", O)):
         if t.device != dev:
@@ -92,8 +102,14 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
         return out, None
     with torch.cuda.device(dev):
         sp = _stream_ptr(dev)
-        need = lib.rtk_workspace_bytes(_lib.RTK_F32, B, R.shape[0], a, b, c)
+        dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
+        need = lib.rtk_workspace_bytes(dcode, B, R.shape[0], a, b, c)
         ws = _workspace(dev, sp, need)
+        if bf16 and (exact or c > 512):
+            raise RuntimeError("bf16 operands: only the bf16 MFMA score kernel exists (c <= 512, exact=False)")
+        qv = lib.rtk_query_vectors_bf16 if bf16 else lib.rtk_query_vectors_f32
+        sp_fn = lib.rtk_score_packed_bf16 if bf16 else lib.rtk_score_packed_f32
+        s1vn = lib.rtk_score_1vN_bf16 if bf16 else lib.rtk_score_1vN_f32
         mode = sigmoid_mode or DEFAULT_SIGMOID
         if mode not in ("fast", "exact"):
             raise ValueError(f"sigmoid mode must be 'fast' or 'exact', got {mode!r}")
@@ -104,22 +120,22 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
         if want_v:
             # two-call form so the fp32 query vectors are kept for backward
             v = torch.empty((B, c), dtype=torch.float32, device=dev)
-            use_packed = not exact and c <= 256
+            use_packed = bf16 or (not exact and c <= 256)
             qp = None
             if use_packed:
-                qp = torch.empty(lib.rtk_packed_query_bytes(_lib.RTK_F32, B, c), dtype=torch.uint8, device=dev)
-            _lib.check(lib.rtk_query_vectors_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0],
+                qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev)
+            _lib.check(qv(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0],
                                                  S.data_ptr(), S.shape[0], r.data_ptr(), h.data_ptr(), B,
                                                  v.data_ptr(), qp.data_ptr() if use_packed else None,
-                                                 ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_f32")
+                                                 ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors")
             if use_packed:
-                _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
+                _lib.check(sp_fn(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
                                                     sflags, sp), "rtk_score_packed_f32")
             else:
                 _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
                                              flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
         else:
-            _lib.check(lib.rtk_score_1vN_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0],
+            _lib.check(s1vn(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0],
                                              S.data_ptr(), S.shape[0], O.data_ptr(), N,
                                              r.data_ptr(), h.data_ptr(), B, out.data_ptr(), ld, flags,
                                              ws.data_ptr(), ws.numel(), sp), "rtk_score_1vN_f32")
@@ -138,6 +154,9 @@ class _Score1vN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         core, R, S, O, h, r, v, out = ctx.saved_tensors
+        pdt = core.dtype                      # bf16 operands: gradients computed in fp32, returned in bf16
+        if pdt != torch.float32:
+            core, R, S, O = core.float(), R.float(), S.float(), O.float()
         dZ = grad_out * out * (1 - out) if ctx.sigmoid else grad_out
         dZ = dZ.contiguous()
         gO = dZ.t() @ v if ctx.needs_input_grad[3] else None                 # (N, c)
@@ -150,6 +169,8 @@ class _Score1vN(torch.autograd.Function):
             gR = torch.zeros_like(R).index_add_(0, r, torch.einsum("dab,db->da", W, Sb))
         if ctx.needs_input_grad[2]:
             gS = torch.zeros_like(S).index_add_(0, h, torch.einsum("dab,da->db", W, Rb))
+        if pdt != torch.float32:
+            gcore, gR, gS, gO = [g.to(pdt) if g is not None else None for g in (gcore, gR, gS, gO)]
         # symmetric model: S and O are the same tensor passed twice; autograd sums gS + gO
         return gcore, gR, gS, gO, None, None, None, None, None
 
