@@ -37,6 +37,8 @@ import gen  # noqa: E402
 WORKLOADS = {
     # name: (n_ent, n_rel, batch, rank, dtype)
     "wn18rr_asym_r10x200_b512_f32": (40943, 22, 512, (10, 200, 200), "f32"),
+    # BASELINE.json configs[2] (parity-test case, selectable for measurements; not the default bench line)
+    "fb15k237_sym_r200x200_b2048_bf16": (14541, 474, 2048, (200, 200, 200), "bf16"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -104,7 +106,13 @@ def main():
 
     n_ent, n_rel, B, trank, dtype = WORKLOADS[args.workload]
     a, b, c = trank
-    core, R, S, O = [torch.from_numpy(x).to(dev) for x in gen.make_params(n_ent, n_rel, trank, 322)]
+    sym = "_sym_" in args.workload
+    core, R, S, O = [torch.from_numpy(x).to(dev) for x in gen.make_params(n_ent, n_rel, trank, 322, shared=sym)]
+    bf16 = dtype == "bf16"
+    if bf16:
+        core, R, S, O = [x.to(torch.bfloat16) for x in (core, R, S, O)]
+    dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
+    esz = 2 if bf16 else 4
     pool_cpu = [tuple(torch.from_numpy(x) for x in gen.make_queries(n_ent, n_rel, B, 1000 + i)) for i in range(64)]
     pool = [(h.to(dev), r.to(dev)) for h, r in pool_cpu]
 
@@ -112,7 +120,7 @@ def main():
     n_loc = -(-n_ent // world)
     lo = min(rank * n_loc, n_ent)
     hi = min(lo + n_loc, n_ent)
-    O_loc = torch.zeros((n_loc, c), dtype=torch.float32, device=dev)
+    O_loc = torch.zeros((n_loc, c), dtype=O.dtype, device=dev)
     O_loc[: hi - lo] = O[lo:hi]                       # last shard zero-padded to equal size
     # rank p's (B, n_loc) block is slot p of the gather buffer: the kernel writes its block in place
     gathered = torch.empty((world, B, n_loc), dtype=torch.float32, device=dev)
@@ -120,13 +128,17 @@ def main():
 
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
-    ws = torch.zeros(lib.rtk_workspace_bytes(_lib.RTK_F32, B, n_rel, a, b, c), dtype=torch.uint8, device=dev)
-    qp = torch.empty(lib.rtk_packed_query_bytes(_lib.RTK_F32, B, c), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.rtk_workspace_bytes(dcode, B, n_rel, a, b, c), dtype=torch.uint8, device=dev)
+    qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev)
+    qv_fn = lib.rtk_query_vectors_bf16 if bf16 else lib.rtk_query_vectors_f32
+    sp_fn = lib.rtk_score_packed_bf16 if bf16 else lib.rtk_score_packed_f32
+    if bf16 and args.exact:
+        raise SystemExit("--exact is an fp32 kernel")
     v = torch.empty((B, c), dtype=torch.float32, device=dev)
 
     def step(i, ev=None):
         h, r = pool[i % len(pool)]
-        _lib.check(lib.rtk_query_vectors_f32(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent,
+        _lib.check(qv_fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent,
                                              r.data_ptr(), h.data_ptr(), B, v.data_ptr() if args.exact else None,
                                              None if args.exact else qp.data_ptr(), ws.data_ptr(), ws.numel(), sp),
                    "rtk_query_vectors_f32")
@@ -136,7 +148,7 @@ def main():
             _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
                                          _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
         else:
-            _lib.check(lib.rtk_score_packed_f32(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
+            _lib.check(sp_fn(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
                                                 sflags, sp), "rtk_score_packed_f32")
         if ev:
             ev[1].record(stream)
@@ -172,7 +184,7 @@ def main():
     gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if world > 1 else None
     # algorithmic bytes of ONE score-kernel launch: read the O shard once, write the scores once,
     # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
-    alg_bytes = n_loc * c * 4 + B * n_loc * 4 + B * c * 4
+    alg_bytes = n_loc * c * esz + B * n_loc * 4 + B * c * esz
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if they match
     try:
@@ -185,16 +197,16 @@ def main():
     result = {
         "metric": "1-vs-N triples scored/sec", "value": args.steps * B / dt, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": args.workload, "entities": n_ent, "relations": n_rel, "rank": list(trank),
                    "batch": B, "scores_per_query": n_ent,
-                   "score_kernel": "exact_f32_mfma" if args.exact else "split_fp16_mfma",
+                   "score_kernel": "exact_f32_mfma" if args.exact else ("bf16_mfma" if bf16 else "split_fp16_mfma"),
                    "sigmoid": "exact" if args.exact else sig_mode,
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
         "scores_per_s": args.steps * B * n_ent / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "score_ws_kernel" if not args.exact else "gemm_f32_kernel",
+                     "kernel": ("score_bf16_kernel" if bf16 else "score_ws_kernel") if not args.exact else "gemm_f32_kernel",
                      "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
     }
     if world > 1:
@@ -205,7 +217,7 @@ def main():
                               "bytes_received_per_gpu": recv, "achieved_GBps": recv / (gather_ms * 1e-3) / 1e9,
                               "xgmi_peak_GBps": 7 * 153.0, "frac": recv / (gather_ms * 1e-3) / 1e9 / (7 * 153.0),
                               "shard_local_queries_per_s": B / (kern_ms * 1e-3)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not bf16:
         result["cpu_baseline"] = cpu_baseline(n_ent, n_rel, B, trank, pool_cpu)
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -152,6 +152,17 @@ int rtk_gemm_f32(const float *A, int a_kmajor, int64_t lda,
                  float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                  unsigned flags, void *stream);
 
+/* Split-K variant for short-and-wide products (K >> M, N), e.g. the backward product
+ * dv = dZ . O (K = number of entities): C (contiguous, ldc == N) is zeroed and the K chunks are
+ * combined with float atomics. */
+int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda,
+                        const float *B, int b_kmajor, int64_t ldb,
+                        float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                        int splits, void *stream);
+
+/* Backward of the logistic (R_TuckER.py:48): dZ = dP * P * (1 - P), n contiguous elements. */
+int rtk_sigmoid_grad_f32(const float *dP, const float *P, float *dZ, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

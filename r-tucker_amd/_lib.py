@@ -36,6 +36,8 @@ SIGNATURES = {
     "rtk_score_packed_bf16": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _u, _p]),
     "rtk_score_1vN_bf16": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _u, _p, _sz, _p]),
     "rtk_gemm_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _u, _p]),
+    "rtk_gemm_f32_splitk": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _i, _p]),
+    "rtk_sigmoid_grad_f32": (_i, [_p, _p, _p, _i64, _p]),
 }
 
 _lib = None

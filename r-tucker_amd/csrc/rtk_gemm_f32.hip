@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const T *__restrict__ A, int64_t lda, const int32_t *__restrict__ a_rows, bool a_vec,
     const T *__restrict__ B, int64_t ldb, bool b_vec,
     float *__restrict__ C, int64_t ldc, int M, int N, int K,
-    const uint32_t *__restrict__ m_dev) {
+    const uint32_t *__restrict__ m_dev, int k_chunk) {
     __shared__ __attribute__((aligned(16))) float As[BK * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
 
@@ -133,10 +133,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         if (B_KMAJOR) store_kmajor(sb, Bs, t); else store_mmajor(sb, Bs, t);
     };
 
-    load(0);
+    // split-K: blockIdx.z owns k in [kb, ke); partial sums are combined with float atomics
+    // (C zeroed by the launcher).  k_chunk == 0: the whole K, plain stores.
+    const bool split = k_chunk > 0;
+    const int kb = split ? blockIdx.z * k_chunk : 0;
+    const int ke = split ? min(K, kb + k_chunk) : K;
+    if (kb >= ke) return;
+    K = ke;
+    load(kb);
     stash();
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    for (int k0 = kb; k0 < K; k0 += BK) {
         const bool more = k0 + BK < K;
         if (more) load(k0 + BK);
 #pragma unroll
@@ -170,7 +177,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
                 if (m < M && n < N) {
                     float x = acc[i][j][e];
                     if (SIGMOID) x = rtk_sigmoid(x);
-                    C[(int64_t)m * ldc + n] = x;
+                    if (split) atomicAdd(&C[(int64_t)m * ldc + n], x);
+                    else C[(int64_t)m * ldc + n] = x;
                 }
             }
         }
@@ -179,10 +187,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 template <typename T, bool AK, bool BK_, bool SG>
 void launch(const T *A, int64_t lda, const int32_t *a_rows, bool a_vec, const T *B, int64_t ldb,
             bool b_vec, float *C, int64_t ldc, int M, int N, int K, const uint32_t *m_dev,
-            hipStream_t st) {
-    dim3 grid((unsigned)rtk_cdiv(N, BN), (unsigned)rtk_cdiv(M, BM));
+            hipStream_t st, int k_chunk = 0) {
+    dim3 grid((unsigned)rtk_cdiv(N, BN), (unsigned)rtk_cdiv(M, BM), (unsigned)(k_chunk > 0 ? rtk_cdiv(K, k_chunk) : 1));
     hipLaunchKernelGGL((gemm_f32_kernel<T, AK, BK_, SG>), grid, dim3(256), 0, st, A, lda, a_rows, a_vec, B,
-                       ldb, b_vec, C, ldc, M, N, K, m_dev);
+                       ldb, b_vec, C, ldc, M, N, K, m_dev, k_chunk);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -194,14 +202,14 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <typename T>
 static int gemm_dispatch(const T *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const T *B, int b_kmajor,
                          int64_t ldb, float *C, int64_t ldc, int m, int n, int k, bool sg, const uint32_t *m_dev,
-                         hipStream_t st) {
+                         hipStream_t st, int k_chunk = 0) {
     constexpr uintptr_t VA = rtk_vec4_align<T>();
     const bool a_vec = ((reinterpret_cast<uintptr_t>(A) & (VA - 1)) == 0) && (lda % 4 == 0);
     const bool b_vec = ((reinterpret_cast<uintptr_t>(B) & (VA - 1)) == 0) && (ldb % 4 == 0);
 #define RTK_GO(AK, BK_)                                                                                        \
     do {                                                                                                       \
-        if (sg) launch<T, AK, BK_, true>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st);    \
-        else launch<T, AK, BK_, false>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st);      \
+        if (sg) launch<T, AK, BK_, true>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st, k_chunk);    \
+        else launch<T, AK, BK_, false>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st, k_chunk);      \
     } while (0)
     if (a_kmajor && b_kmajor) RTK_GO(true, true);
     else if (a_kmajor && !b_kmajor) RTK_GO(true, false);
@@ -245,4 +253,54 @@ extern "C" int rtk_score_f32(const float *v, int64_t batch, int c, const float *
     RTK_REQUIRE(c > 0, RTK_ERR_BAD_ARG, "rtk_score_f32: c must be positive");
     return rtk_gemm_f32_ex(v, 1, c, nullptr, O, 1, c, out, ld_out, batch, n_local, c,
                            flags & RTK_SCORE_SIGMOID, nullptr, 0, (hipStream_t)stream);
+}
+
+// Split-K form for short-and-wide products (e.g. dv = dZ . O with K = n_entities): C is zeroed,
+// K is cut into `splits` chunks handled by separate workgroups, partial tiles are added with
+// float atomics (run-to-run summation order is not fixed: last-bit differences between runs).
+extern "C" int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda, const float *B, int b_kmajor,
+                                   int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int splits,
+                                   void *stream) {
+    RTK_REQUIRE(A && B && C, RTK_ERR_BAD_ARG, "rtk_gemm_f32_splitk: null operand");
+    RTK_REQUIRE(M > 0 && N > 0 && K > 0 && splits > 0, RTK_ERR_BAD_ARG, "rtk_gemm_f32_splitk: sizes must be positive");
+    RTK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_gemm_f32_splitk: dimension exceeds 2^31-1");
+    RTK_REQUIRE(ldc == N, RTK_ERR_BAD_ARG, "rtk_gemm_f32_splitk: C must be contiguous (ldc == N)");
+    RTK_REQUIRE(rtk_cdiv(M, BM) <= 65535 && splits <= 65535, RTK_ERR_UNSUPPORTED, "rtk_gemm_f32_splitk: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
+    if (e != hipSuccess) {
+        rtk_set_error("rtk_gemm_f32_splitk: memset: %s", hipGetErrorString(e));
+        return RTK_ERR_LAUNCH;
+    }
+    int k_chunk = (int)rtk_cdiv(rtk_cdiv(K, splits), BK) * BK;
+    return gemm_dispatch<float>(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, C, ldc, (int)M, (int)N, (int)K, false,
+                                nullptr, st, k_chunk);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void sigmoid_grad_kernel(const float *__restrict__ dP, const float *__restrict__ P,
+                                                           float *__restrict__ dZ, int64_t n4, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 g = reinterpret_cast<const f32x4 *>(dP)[i], p = reinterpret_cast<const f32x4 *>(P)[i];
+        f32x4 z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] = g[q] * p[q] * (1.0f - p[q]);
+        reinterpret_cast<f32x4 *>(dZ)[i] = z;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) dZ[i] = dP[i] * P[i] * (1.0f - P[i]);
+}
+}  // namespace
+
+// dZ = dP * P * (1 - P): the logistic's derivative applied to the incoming gradient (backward of
+// R_TuckER.py:48).  All three arrays are contiguous with n elements; dZ may alias dP.
+extern "C" int rtk_sigmoid_grad_f32(const float *dP, const float *P, float *dZ, int64_t n, void *stream) {
+    RTK_REQUIRE(dP && P && dZ && n > 0, RTK_ERR_BAD_ARG, "rtk_sigmoid_grad_f32: bad argument");
+    const bool al = ((reinterpret_cast<uintptr_t>(dP) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(dZ)) & 15) == 0;
+    const int64_t n4 = al ? n / 4 : 0;
+    const int64_t blocks = n4 > 0 ? rtk_cdiv(n4, 256) : 1;
+    hipLaunchKernelGGL(sigmoid_grad_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, dP, P, dZ, n4, n);
+    return rtk_check_launch("rtk_sigmoid_grad_f32");
 }

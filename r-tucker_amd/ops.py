@@ -2,10 +2,12 @@
 
 ``score_1vN`` is what ``score_fn(T)`` of both model flavours calls; it replaces the
 five torch ops of ``src/model/asymmetric/R_TuckER.py:43-48`` with one call into the
-C ABI (``rtk_score_1vN_f32``).  Forward runs entirely in the hand-written HIP
-kernels.  Backward (needed because the optimizer differentiates ``loss_fn(T)``,
-``train.py:79-82``) currently composes device-side torch ops around the saved
-query vectors; it never leaves the GPU.
+C ABI (``rtk_score_1vN_f32`` / ``_bf16``).  Forward runs entirely in the hand-written
+HIP kernels.  Backward (needed because the optimizer differentiates ``loss_fn(T)``,
+``train.py:79-82``): the three B x N-sized steps -- logistic derivative, dO = dZ^T v,
+dv = dZ O -- are HIP kernels (``rtk_sigmoid_grad_f32``, ``rtk_gemm_f32``,
+``rtk_gemm_f32_splitk``); the small trilinear remainder (gradients of core, R, S from
+dv) is device-side torch ops.  Nothing leaves the GPU.
 """
 from __future__ import annotations
 
@@ -157,10 +159,31 @@ class _Score1vN(torch.autograd.Function):
         pdt = core.dtype                      # bf16 operands: gradients computed in fp32, returned in bf16
         if pdt != torch.float32:
             core, R, S, O = core.float(), R.float(), S.float(), O.float()
-        dZ = grad_out * out * (1 - out) if ctx.sigmoid else grad_out
-        dZ = dZ.contiguous()
-        gO = dZ.t() @ v if ctx.needs_input_grad[3] else None                 # (N, c)
-        dv = dZ @ O                                                          # (B, c)
+        lib = _lib.load()
+        dev = out.device
+        B, N = out.shape
+        c = O.shape[1]
+        grad_out = grad_out.contiguous().float()
+        with torch.cuda.device(dev):
+            sp = _stream_ptr(dev)
+            if ctx.sigmoid:      # dZ = dP * P * (1 - P)   (HIP)
+                dZ = torch.empty_like(out)
+                _lib.check(lib.rtk_sigmoid_grad_f32(grad_out.data_ptr(), out.data_ptr(), dZ.data_ptr(), out.numel(), sp),
+                           "rtk_sigmoid_grad_f32")
+            else:
+                dZ = grad_out
+            gO = None
+            if ctx.needs_input_grad[3]:
+                # gO[j, k] = sum_d dZ[d, j] * v[d, k]   -- fp32 MFMA GEMM, both operands M-major
+                gO = torch.empty((N, c), dtype=torch.float32, device=dev)
+                _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, N, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
+                           "rtk_gemm_f32 (dO)")
+            # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K with float atomics
+            Of = O.contiguous()
+            dv = torch.empty((B, c), dtype=torch.float32, device=dev)
+            splits = max(1, min(256, N // 512))
+            _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, N, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
+                                               splits, sp), "rtk_gemm_f32_splitk (dv)")
         Rb, Sb = R[r], S[h]
         W = torch.einsum("abc,dc->dab", core, dv)                            # (B, a, b)
         gcore = torch.einsum("da,db,dc->abc", Rb, Sb, dv) if ctx.needs_input_grad[0] else None

@@ -208,3 +208,40 @@ def test_gemm_f32_layouts(rt, layout):
     assert rc == 0, lib.rtk_last_error_string()
     ref = A.astype(np.float64) @ Bm.astype(np.float64).T
     assert np.max(np.abs(C.cpu().numpy() - ref)) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["asym", "sym"])
+def test_gradients_medium_against_oracle_autograd(rt, mode):
+    """Backward through the HIP path (sigmoid-grad kernel, fp32 MFMA GEMM for dO, split-K GEMM
+    for dv) against torch autograd through the oracle's op sequence on CPU."""
+    n_ent, n_rel, B, rank = 3000, 7, 96, (6, 40, 40)
+    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 9, shared=(mode == "sym"))
+    h, r = gen.make_queries(n_ent, n_rel, B, 9)
+    w = np.random.default_rng(9).standard_normal((B, n_ent)).astype(np.float32)
+    ref = orc.score_grads_ref(*[torch.from_numpy(x) for x in (core, R, S, O, h, r)], torch.from_numpy(w),
+                              shared=(mode == "sym"))
+    leaves = [t.requires_grad_(True) for t in dev(core, R, S)]
+    if mode == "sym":
+        P = rt.score_1vN(leaves[0], leaves[1], leaves[2], leaves[2], *dev(h, r))
+    else:
+        leaves.append(torch.from_numpy(O).cuda().requires_grad_(True))
+        P = rt.score_1vN(leaves[0], leaves[1], leaves[2], leaves[3], *dev(h, r))
+    (P * torch.from_numpy(w).cuda()).sum().backward()
+    for leaf, g in zip(leaves, ref):
+        scale = g.abs().max().item() + 1e-12
+        assert (leaf.grad.cpu() - g).abs().max().item() / scale < 2e-4
+
+
+def test_gemm_splitk_against_float64(rt):
+    lib = rt._lib.load()
+    M, N, K = 96, 40, 5000
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)      # B(n, k) = Bm[k, n]: M-major
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(Bm).cuda()
+    C = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")   # must be overwritten, not accumulated into
+    rc = lib.rtk_gemm_f32_splitk(dA.data_ptr(), 1, K, dB.data_ptr(), 0, N, C.data_ptr(), N, M, N, K, 9,
+                                 torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.rtk_last_error_string()
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    assert np.max(np.abs(C.cpu().numpy() - ref)) < 2e-3
