@@ -3,21 +3,26 @@
 
 namespace {
 
-template <int KS, int SG>
-void launch_one(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
-                bool o_vec, hipStream_t st) {
+template <int KS, int SG, bool OV>
+void launch_v(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld, hipStream_t st) {
     const size_t smem = rtk_ws::lds_bytes<KS>(c);
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the attribute (idempotent)
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<KS, SG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<KS, SG, OV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     // one resident workgroup per CU; the kernel cuts the (entity tile x query tile) space evenly
     const int64_t units = rtk_cdiv(N, 128) * rtk_cdiv(B, 32);
     const unsigned grid = (unsigned)(units < 256 ? units : 256);
-    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<KS, SG>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld,
-                       o_vec);
+    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<KS, SG, OV>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld);
+}
+
+template <int KS, int SG>
+void launch_one(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
+                bool o_vec, hipStream_t st) {
+    if (o_vec) launch_v<KS, SG, true>(qp, B, O, N, c, out, ld, st);
+    else launch_v<KS, SG, false>(qp, B, O, N, c, out, ld, st);
 }
 
 template <int KS>

@@ -66,9 +66,9 @@ struct Sched {
     }
 };
 
-template <int KS, bool STAMP, unsigned XP>
+template <int KS, bool STAMP, unsigned XP, bool o_vec>
 __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict__ q_packed, unsigned char *stg,
-                                       unsigned char *oreg, bool o_vec, int lane, int w4, int ht) {
+                                       unsigned char *oreg, int lane, int w4, int ht) {
     constexpr int TILE_BYTES = tile_bytes<KS>();
     constexpr int CHUNKS = TILE_BYTES / 16;
     constexpr int NLD = (CHUNKS + 255) / 256;   // staging 16-B chunks per M thread
@@ -94,45 +94,63 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
         f16x8 Bh[KS], Bl[KS];
         float us_o;
         {
+            // Fragment reads go out in batches of 4 k-steps (8 ds_read_b128 in flight, branch-free:
+            // an out-of-row float4 is read from column 0 and zeroed by a select) before anything
+            // consumes them; read -> use pairs expose one LDS latency per read (3.5 us per tile).
             const float *lrow = reinterpret_cast<const float *>(oreg) + (w4 * 32 + r) * c;
-            auto frag8 = [&](int ks, float (&x)[8]) {   // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
-                const int k = 16 * ks + 8 * h;
-                if (o_vec) {  // c % 4 == 0: 16-B aligned rows; a float4 is wholly inside or outside
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-                    if (k + 4 <= c) a = *reinterpret_cast<const f32x4 *>(lrow + k);
-                    if (k + 8 <= c) b = *reinterpret_cast<const f32x4 *>(lrow + k + 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        x[q] = a[q];
-                        x[4 + q] = b[q];
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) x[q] = (k + q < c) ? lrow[k + q] : 0.f;
-                }
-            };
+            constexpr int CB = 4;
             float mx = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                float x[8];
-                frag8(ks, x);
+            for (int pass = 0; pass < 2; ++pass) {
+                float up = 1.f;
+                if (pass == 1) {
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const int sh = rtk_pack_shift(mx);
+                    up = ldexpf(1.0f, sh);
+                    us_o = ldexpf(1.0f, -sh);
+                }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) mx = fmaxf(mx, fabsf(x[q]));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const int sh = rtk_pack_shift(mx);
-            const float up = ldexpf(1.0f, sh);
-            us_o = ldexpf(1.0f, -sh);
+                for (int ks0 = 0; ks0 < KS; ks0 += CB) {
+                    f32x4 ta[CB], tb[CB];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                float x[8];
-                frag8(ks, x);
+                    for (int u = 0; u < CB; ++u) {
+                        const int k = 16 * (ks0 + u) + 8 * h;   // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
+                        if (ks0 + u < KS) {
+                            if (o_vec) {  // c % 4 == 0: 16-B aligned rows; a float4 is wholly inside or outside the row
+                                ta[u] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
+                                tb[u] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
+                            } else {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float y = x[q] * up;
-                    const _Float16 hi = (_Float16)y;
-                    Bh[ks][q] = hi;
-                    Bl[ks][q] = (_Float16)(y - (float)hi);
+                                for (int q = 0; q < 4; ++q) {
+                                    ta[u][q] = lrow[(k + q < c) ? k + q : 0];
+                                    tb[u][q] = lrow[(k + 4 + q < c) ? k + 4 + q : 0];
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) {
+                        const int ks = ks0 + u;
+                        const int k = 16 * ks + 8 * h;
+                        if (ks < KS) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const bool ok0 = o_vec ? (k + 4 <= c) : (k + q < c);
+                                const bool ok1 = o_vec ? (k + 8 <= c) : (k + 4 + q < c);
+                                const float x0 = ok0 ? ta[u][q] : 0.f, x1 = ok1 ? tb[u][q] : 0.f;
+                                if (pass == 0) {
+                                    mx = fmaxf(mx, fmaxf(fabsf(x0), fabsf(x1)));
+                                } else {
+                                    const float y0 = x0 * up, y1 = x1 * up;
+                                    const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+                                    Bh[ks][q] = h0;
+                                    Bh[ks][4 + q] = h1;
+                                    Bl[ks][q] = (_Float16)(y0 - (float)h0);
+                                    Bl[ks][4 + q] = (_Float16)(y1 - (float)h1);
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -351,10 +369,12 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int KS, int SIGMOID, bool STAMP = false, unsigned XP = 0>
+// O_VEC: c % 4 == 0 and O 16-B aligned (compile-time so the scalar fallback's address arithmetic
+// is not hoisted into -- and spilled by -- the vector build)
+template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0>
 __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
-    float *__restrict__ out, int64_t ld_out, bool o_vec) {
+    float *__restrict__ out, int64_t ld_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *const stg = lds;
     unsigned char *const oreg = lds + 2 * tile_bytes<KS>();
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     sc.lin = U * blockIdx.x / gridDim.x;
     sc.lin_end = U * (blockIdx.x + 1) / gridDim.x;
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
-    if (__builtin_amdgcn_readfirstlane(wave) < 4) m_role<KS, STAMP, XP>(sc, q_packed, stg, oreg, o_vec, lane, wave & 3, t & 255);
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) m_role<KS, STAMP, XP, O_VEC>(sc, q_packed, stg, oreg, lane, wave & 3, t & 255);
     else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, wave & 3, t & 255);
 }
 

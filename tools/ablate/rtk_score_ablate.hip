@@ -38,9 +38,9 @@ extern "C" int rtk_ablate_score_packed_f32(const void *qp, int64_t B, int c, con
 template <unsigned XP>
 static int ws_go(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld, int grid, void *stream) {
     const size_t smem = rtk_ws::lds_bytes<13>(c);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<13, 2, true, XP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<13, 2, true, true, XP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<13, 2, true, XP>), dim3(grid), dim3(512), smem, (hipStream_t)stream,
+    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<13, 2, true, true, XP>), dim3(grid), dim3(512), smem, (hipStream_t)stream,
                        (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld, c % 4 == 0);
     return (int)hipGetLastError();
 }
