@@ -163,6 +163,23 @@ int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda,
 /* Backward of the logistic (R_TuckER.py:48): dZ = dP * P * (1 - P), n contiguous elements. */
 int rtk_sigmoid_grad_f32(const float *dP, const float *P, float *dZ, int64_t n, void *stream);
 
+/*
+ * Filtered rank of the queried object, on the device -- replaces the full B x N sort of the
+ * eval tail (train.py:115-117; src/utils/utils.py:15-22 filter_predictions + src/utils/metrics.py:5-8).
+ *   P          (batch x ld) scores, as written by the score stage (not modified)
+ *   obj_idx    queried object id per row (features[:, 2])
+ *   pair_slot  per row, index into the CSR of known-true objects of its (subject, relation)
+ *              pair, or NULL for "no filtering"; pair_ptr / pair_obj: that CSR (int64)
+ *   ranks_out  int32: 1 + #{j: p'_j > p_t} + #{j < t: p'_j == p_t}, p' = scores with the other
+ *              true objects set to 0  (= position in a stable descending sort)
+ *   bce_rows_out  optional double[batch]: per-row sum of nn.BCELoss terms against the 0/1 targets
+ *              (train.py:113), logs clamped at -100 like torch; NULL to skip
+ */
+int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t ld,
+                          const int64_t *obj_idx, const int64_t *pair_slot,
+                          const int64_t *pair_ptr, const int64_t *pair_obj,
+                          int32_t *ranks_out, double *bce_rows_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

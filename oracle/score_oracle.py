@@ -187,3 +187,22 @@ def filter_and_rank(predictions, targets, object_idx):
     p, t = filter_predictions_ref(p, t, object_idx.reshape(-1, 1))
     ranks, _ = ranks_ref(p, t)
     return ranks, metrics_ref(p, t)
+
+
+def ranks_stable_ref(predictions, targets):
+    """Ranks under a STABLE descending sort (tied scores keep index order) -- the order torch's
+    CUDA sort gives the reference; ``metrics.py:5`` itself calls ``torch.sort`` with the default
+    ``stable=False``, whose CPU tie order is unspecified."""
+    _, idx = torch.sort(predictions, dim=1, descending=True, stable=True)
+    return targets.gather(1, idx).argmax(dim=1) + 1
+
+
+def filter_and_rank_stable(predictions, targets, object_idx):
+    p, t = predictions.clone(), targets.clone()
+    p, t = filter_predictions_ref(p, t, object_idx.reshape(-1, 1))
+    return ranks_stable_ref(p, t)
+
+
+def bce_mean_ref(predictions, targets):
+    """``nn.BCELoss(reduction="mean")(predictions, targets)`` -- train.py:113,136."""
+    return torch.nn.functional.binary_cross_entropy(predictions, targets, reduction="mean")

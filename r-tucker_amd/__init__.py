@@ -10,6 +10,7 @@ from .tucker import Tucker, SFTucker  # noqa: F401
 from .ops import score_1vN, score_1vN_into, query_vectors, check_device_errors  # noqa: F401
 from .sharded import EntityShards, ShardedEntityScorer  # noqa: F401
 from . import _lib  # noqa: F401
+from .evaluation import DeviceFilter, evaluate, filtered_ranks, metrics_from_ranks  # noqa: F401
 from .model.asymmetric import R_TuckER as AsymmetricR_TuckER  # noqa: F401
 from .model.symmetric import R_TuckER as SymmetricR_TuckER  # noqa: F401
 

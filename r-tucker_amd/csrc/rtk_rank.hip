@@ -1,0 +1,83 @@
+// Filtered ranking on the device (the eval tail of the reference, train.py:113-117):
+//   filter_predictions (src/utils/utils.py:15-22): scores of the OTHER known-true objects of a
+//     query are replaced by 0, the queried object keeps its score;
+//   metrics (src/utils/metrics.py:4-22): rank of the queried object in the descending sort.
+// The reference does a full sort of B x N (150 ms per batch on CPU).  Here one
+// workgroup per query counts, in a single pass over its score row,
+//     rank = 1 + #{ j : p'_j > p_t } + #{ j < t : p'_j == p_t }
+// i.e. the position in a STABLE descending sort (what torch's CUDA radix sort and
+// sort(stable=True) produce; torch's default CPU sort is unstable, so the reference's own
+// tie order on CPU is unspecified).  Optionally it also returns the row's BCE sum
+// (nn.BCELoss with 0/1 targets, logs clamped at -100 like torch), train.py:113.
+#include "rtk_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void filtered_rank_kernel(
+    const float *__restrict__ P, int B, int N, int64_t ld, const int64_t *__restrict__ obj_idx,
+    const int64_t *__restrict__ pair_slot, const int64_t *__restrict__ pair_ptr,
+    const int64_t *__restrict__ pair_obj, int32_t *__restrict__ ranks, double *__restrict__ bce_rows) {
+    __shared__ int s_gt[4], s_eq[4];
+    __shared__ float s_bce[4];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const float *row = P + (int64_t)d * ld;
+    int64_t tgt = obj_idx[d];
+    tgt = tgt < 0 ? 0 : (tgt >= N ? N - 1 : tgt);
+    const float pt = row[tgt];
+    int gt = 0, eq = 0;
+    float bce = 0.f;
+    const bool want_bce = bce_rows != nullptr;
+    for (int j = t; j < N; j += 256) {
+        const float p = row[j];
+        gt += p > pt;
+        eq += (p == pt) & (j < tgt);
+        if (want_bce) bce += fmaxf(logf(1.0f - p), -100.0f);
+    }
+    // the query's other true objects count as score 0 (and, for BCE, as positives)
+    const int64_t s = pair_slot ? pair_slot[d] : -1;
+    if (s >= 0) {
+        for (int64_t i = pair_ptr[s] + t; i < pair_ptr[s + 1]; i += 256) {
+            const int64_t j = pair_obj[i];
+            if (j < 0 || j >= N) continue;
+            const float p = row[j];
+            if (want_bce) bce += fmaxf(logf(p), -100.0f) - fmaxf(logf(1.0f - p), -100.0f);
+            if (j == tgt) continue;
+            gt -= p > pt;
+            eq -= (p == pt) & (j < tgt);
+            eq += (0.0f == pt) & (j < tgt);     // now a 0: ties only with a zero target score
+        }
+    } else if (want_bce && t == 0) {            // no filter list: the queried object is the only positive
+        bce += fmaxf(logf(pt), -100.0f) - fmaxf(logf(1.0f - pt), -100.0f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        gt += __shfl_xor(gt, o);
+        eq += __shfl_xor(eq, o);
+        bce += __shfl_xor(bce, o);
+    }
+    if ((t & 63) == 0) {
+        s_gt[t >> 6] = gt;
+        s_eq[t >> 6] = eq;
+        s_bce[t >> 6] = bce;
+    }
+    __syncthreads();
+    if (t == 0) {
+        ranks[d] = 1 + s_gt[0] + s_gt[1] + s_gt[2] + s_gt[3] + s_eq[0] + s_eq[1] + s_eq[2] + s_eq[3];
+        if (want_bce) bce_rows[d] = -((double)s_bce[0] + (double)s_bce[1] + (double)s_bce[2] + (double)s_bce[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t ld,
+                                     const int64_t *obj_idx, const int64_t *pair_slot, const int64_t *pair_ptr,
+                                     const int64_t *pair_obj, int32_t *ranks_out, double *bce_rows_out,
+                                     void *stream) {
+    RTK_REQUIRE(P && obj_idx && ranks_out, RTK_ERR_BAD_ARG, "rtk_filtered_rank_f32: null operand");
+    RTK_REQUIRE(batch > 0 && n_ent > 0 && ld >= n_ent, RTK_ERR_BAD_ARG, "rtk_filtered_rank_f32: bad sizes");
+    RTK_REQUIRE(!pair_slot || (pair_ptr && pair_obj), RTK_ERR_BAD_ARG, "rtk_filtered_rank_f32: pair_slot without the CSR arrays");
+    RTK_REQUIRE(batch < (1ll << 31) && n_ent < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_filtered_rank_f32: dimension too large");
+    hipLaunchKernelGGL(filtered_rank_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, P, (int)batch,
+                       (int)n_ent, ld, obj_idx, pair_slot, pair_ptr, pair_obj, ranks_out, bce_rows_out);
+    return rtk_check_launch("rtk_filtered_rank_f32");
+}

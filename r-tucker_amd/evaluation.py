@@ -1,0 +1,98 @@
+"""Evaluation on the device: the reference's ``evaluate()`` (train.py:94-125) with the
+score path and the ranking tail both in HIP.
+
+``evaluate(model, dataset)`` returns the same dictionary the reference returns --
+``{"mrr", "hits@1", "hits@3", "hits@10"}`` averaged over the queries, plus the mean BCE
+loss -- but never builds the dense (B, N) target matrix on the host and never sorts:
+the filter lists of every (subject, relation) pair are uploaded once as a CSR and
+``rtk_filtered_rank_f32`` counts the rank of the queried object in one pass over the
+score row.  Tie order is that of a stable descending sort (torch's CUDA sort /
+``sort(stable=True)``); the reference's default CPU sort is unstable, so on exactly tied
+scores its own ranks are implementation-defined.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .tucker import SFTucker, Tucker
+
+
+class DeviceFilter:
+    """The (subject, relation) -> known-true-objects CSR of a ``KG_dataset`` on the device."""
+
+    def __init__(self, dataset, device):
+        self.device = torch.device(device)
+        self.pair_ptr = torch.as_tensor(np.asarray(dataset._ptr, dtype=np.int64), device=self.device)
+        self.pair_obj = torch.as_tensor(np.asarray(dataset._obj, dtype=np.int64), device=self.device)
+        f = dataset.features
+        slots = np.fromiter((dataset._pair_slot[(int(s), int(r))] for s, r in f[:, :2]), dtype=np.int64, count=len(f))
+        self.slot_of_item = torch.as_tensor(slots, device=self.device)
+        self.features = torch.as_tensor(np.asarray(f, dtype=np.int64), device=self.device)
+
+
+def filtered_ranks(P: torch.Tensor, obj_idx: torch.Tensor, flt: DeviceFilter = None, item_ids: torch.Tensor = None,
+                   want_bce: bool = False):
+    """Ranks (int32, B) of ``obj_idx`` in the rows of ``P`` after filtering; optionally the per-row BCE sums."""
+    lib = _lib.load()
+    if not P.is_cuda or P.dtype != torch.float32 or P.dim() != 2 or P.stride(1) != 1:
+        raise RuntimeError("P must be a float32 (B, N) GPU tensor with unit column stride")
+    B, N = P.shape
+    dev = P.device
+    obj = obj_idx.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+    if obj.numel() != B:
+        raise RuntimeError("obj_idx must have one entry per row of P")
+    ranks = torch.empty(B, dtype=torch.int32, device=dev)
+    bce = torch.empty(B, dtype=torch.float64, device=dev) if want_bce else None
+    slot = ptr = objs = None
+    if flt is not None:
+        slot = flt.slot_of_item[item_ids.to(dev)].contiguous()
+        ptr, objs = flt.pair_ptr, flt.pair_obj
+    with torch.cuda.device(dev):
+        sp = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.rtk_filtered_rank_f32(P.data_ptr(), B, N, P.stride(0), obj.data_ptr(),
+                                             slot.data_ptr() if slot is not None else None,
+                                             ptr.data_ptr() if ptr is not None else None,
+                                             objs.data_ptr() if objs is not None else None,
+                                             ranks.data_ptr(), bce.data_ptr() if want_bce else None, sp),
+                   "rtk_filtered_rank_f32")
+    return (ranks, bce) if want_bce else ranks
+
+
+def metrics_from_ranks(ranks: torch.Tensor):
+    """Batch SUMS like ``src/utils/metrics.py`` (mrr = sum 1/rank, hits@k = #(rank <= k))."""
+    r = ranks.to(torch.float64)
+    return {"mrr": (1.0 / r).sum(), "hits@1": (ranks <= 1).sum(), "hits@3": (ranks <= 3).sum(),
+            "hits@10": (ranks <= 10).sum()}
+
+
+@torch.no_grad()
+def evaluate(model, dataset, batch_size=512, device=None, flt: DeviceFilter = None):
+    """The reference's ``evaluate`` loop on the device.  ``dataset``: a test-mode ``KG_dataset``.
+    Returns (metrics dict averaged over queries, mean BCE loss) like train.py:123-125."""
+    device = torch.device(device) if device is not None else next(model.parameters()).device
+    flt = flt or DeviceFilter(dataset, device)
+    if hasattr(model, "E"):
+        T = SFTucker(model.core.data, [model.R.weight], num_shared_factors=2, shared_factor=model.E.weight)
+    else:
+        T = Tucker(model.core.data, [model.R.weight, model.S.weight, model.O.weight])
+    n = len(dataset)
+    sums = {"mrr": 0.0, "hits@1": 0.0, "hits@3": 0.0, "hits@10": 0.0}
+    loss_sum, n_batches = 0.0, 0
+    acc = None
+    for lo in range(0, n, batch_size):
+        ids = torch.arange(lo, min(lo + batch_size, n), device=device)
+        f = flt.features[ids]
+        P = model(f[:, 0], f[:, 1])(T)
+        ranks, bce = filtered_ranks(P, f[:, 2], flt, ids, want_bce=True)
+        m = metrics_from_ranks(ranks)
+        vec = torch.stack([m["mrr"], m["hits@1"].double(), m["hits@3"].double(), m["hits@10"].double(),
+                           bce.sum() / (P.shape[0] * P.shape[1])])
+        acc = vec if acc is None else acc + vec          # stays on the device: one sync at the end
+        n_batches += 1
+    acc = acc.cpu()
+    for k, v in zip(("mrr", "hits@1", "hits@3", "hits@10"), acc[:4].tolist()):
+        sums[k] = v / n
+    loss_sum = acc[4].item()
+    return sums, loss_sum / n_batches

@@ -1,0 +1,88 @@
+"""On-device filtered ranking + BCE (rtk_filtered_rank_f32, r_tucker_amd.evaluation) against the
+oracle's restatement of filter_predictions + metrics.  Integer work: ranks must be IDENTICAL to
+the oracle's under the stated tie rule (stable descending sort)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen
+from oracle import score_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def rt():
+    assert torch.cuda.is_available()
+    import r_tucker_amd
+    r_tucker_amd._lib.load()
+    return r_tucker_amd
+
+
+def test_ranks_tie_heavy_random_rows(rt):
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        B, N = 37, 1000 + 13 * trial
+        P = rng.choice(np.asarray([0.0, 0.1, 0.5, 0.9, 1.0], dtype=np.float32), size=(B, N))
+        t = (rng.random((B, N)) < 0.02).astype(np.float32)
+        o = rng.integers(0, N, B)
+        t[np.arange(B), o] = 1
+        ref = orc.filter_and_rank_stable(torch.from_numpy(P), torch.from_numpy(t), torch.from_numpy(o))
+        # CSR of the true objects per row (slot = row)
+        ptr = np.concatenate([[0], np.cumsum(t.sum(1).astype(np.int64))])
+        objs = np.concatenate([np.nonzero(t[d])[0] for d in range(B)]).astype(np.int64)
+
+        class F:  # minimal stand-in for DeviceFilter
+            pair_ptr = torch.from_numpy(ptr).cuda()
+            pair_obj = torch.from_numpy(objs).cuda()
+            slot_of_item = torch.arange(B).cuda()
+        ranks, bce = rt.filtered_ranks(torch.from_numpy(P).cuda(), torch.from_numpy(o).cuda(), F, torch.arange(B), want_bce=True)
+        np.testing.assert_array_equal(ranks.cpu().numpy(), ref.numpy())
+        ref_bce = orc.bce_mean_ref(torch.from_numpy(P), torch.from_numpy(t)).item()
+        assert abs(bce.sum().item() / (B * N) - ref_bce) <= 1e-5 * max(1.0, abs(ref_bce))
+        # unfiltered form
+        r0 = rt.filtered_ranks(torch.from_numpy(P).cuda(), torch.from_numpy(o).cuda())
+        t1 = np.zeros_like(t)
+        t1[np.arange(B), o] = 1
+        np.testing.assert_array_equal(r0.cpu().numpy(), orc.ranks_stable_ref(torch.from_numpy(P), torch.from_numpy(t1)).numpy())
+
+
+@pytest.mark.parametrize("variant", ["planted", "planted_sat", "spread"])
+def test_device_evaluate_wn18rr(rt, golden, golden_meta, variant):
+    from r_tucker_amd.data import Data, KG_dataset
+    data = Data(os.path.join(ROOT, "data", "WN18RR") + "/", reverse=True)
+    n_ent, n_rel, rank, seed = len(data.entities), len(data.relations), (10, 200, 200), 322
+    test = KG_dataset(data, data.test_data, test_set=True)
+    if variant.startswith("planted"):
+        train = KG_dataset(data, data.train_data, label_smoothing=0.1)
+        valid = KG_dataset(data, data.valid_data, test_set=True)
+        planted = np.concatenate([np.asarray(train.data_index, dtype=np.int64), valid.features[::2], test.features[::2]])
+        params = gen.make_planted_params(planted, n_ent, n_rel, rank, seed, gain=8.0 if variant == "planted" else 40.0)
+    else:
+        params = gen.make_params(n_ent, n_rel, rank, seed)
+    model = rt.AsymmetricR_TuckER((n_ent, n_rel), rank)
+    model.init({"core": torch.from_numpy(params[0]), "R.weight": torch.from_numpy(params[1]),
+                "S.weight": torch.from_numpy(params[2]), "O.weight": torch.from_numpy(params[3])})
+    model.cuda().eval()
+    flt = rt.DeviceFilter(test, "cuda")
+    m, loss = rt.evaluate(model, test, batch_size=512, flt=flt)
+    case = golden_meta["cases"][f"rank_{variant}_test"]
+    print(f"\n{variant}: device MRR {m['mrr']:.6f} (reference, unstable CPU sort: {case['mrr']:.6f})  "
+          f"hits@1 {m['hits@1'] * len(test):.0f}/{case['sums']['hits@1']:.0f}  loss {loss:.5f}")
+    # exact check of one batch against the oracle on the SAME device scores
+    ids = torch.arange(0, 512).cuda()
+    f = flt.features[ids]
+    T = rt.Tucker(model.core.data, [model.R.weight, model.S.weight, model.O.weight])
+    with torch.no_grad():
+        P = model(f[:, 0], f[:, 1])(T)
+    ranks, bce = rt.filtered_ranks(P, f[:, 2], flt, ids, want_bce=True)
+    tg = test.dense_targets(np.arange(512))
+    ref = orc.filter_and_rank_stable(P.cpu(), tg, f[:, 2].cpu())
+    np.testing.assert_array_equal(ranks.cpu().numpy(), ref.numpy())
+    ref_bce = orc.bce_mean_ref(P.cpu(), tg).item()
+    assert abs(bce.sum().item() / P.numel() - ref_bce) <= 2e-5 * max(1.0, abs(ref_bce))
+    if variant != "planted_sat":      # massive exact ties at 1.0: the reference's own CPU tie order is arbitrary there
+        assert abs(m["mrr"] - case["mrr"]) <= 1e-3
