@@ -4,8 +4,9 @@ metric sums the REFERENCE produced from its own scores (tests/golden/wn18rr_rank
 
 Bar (north_star): MRR within +-0.001 of the reference.  Per-query ranks are also
 compared: fp32 sigmoid outputs tie massively near 1.0 and ties are broken by sort
-order, so a 1-ulp difference can move a rank; we require >= 99 %
-of ranks identical and report the rest.
+order, so a 1-ulp difference can move a rank, and torch's default CPU sort is unstable (its tie
+order varies with the host's thread count); we require >= 99 % of ranks identical (>= 97 % on
+the deliberately saturated fixtures) and report the rest.
 """
 import os
 
@@ -71,6 +72,8 @@ def test_filtered_mrr_matches_reference(wn, golden, golden_meta, variant, sigmoi
         print(f"\n{variant}/{split} [{sigmoid_mode}]: MRR hip {mrr:.6f} ref {ref_mrr:.6f}  identical ranks {same:.4%}  "
               f"hits@1 {sums['hits@1']:.0f}/{case['sums']['hits@1']:.0f}")
         assert abs(mrr - ref_mrr) <= 1e-3
-        assert same >= (0.99 if sigmoid_mode == "exact" else 0.97)
+        # exactly tied scores (fp32 sigmoid saturates at 1.0) are ordered by torch's UNSTABLE CPU sort: the tie order --
+        # hence the rank of a tied target -- depends on the host (thread count), both in the golden run and here
+        assert same >= (0.97 if "sat" in variant else 0.99)
         for k in ("hits@1", "hits@3", "hits@10"):
             assert abs(sums[k] - case["sums"][k]) <= 0.002 * len(d) + 1
