@@ -33,7 +33,6 @@ static size_t packed_bytes(int dtype, int64_t batch, int c) {
 }
 
 static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, int a, int b, int c) {
-    (void)a;
     RtkWorkspace w;
     unsigned char *p = (unsigned char *)base;
     size_t off = 0;
@@ -49,6 +48,9 @@ static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, i
     w.tables = (float *)take((size_t)n_u_max * b * c * 4);
     w.v = (float *)take((size_t)batch * c * 4);
     w.q_packed = take(packed_bytes(dtype, batch, c));
+    const bool big_a = dtype == RTK_BF16 && a > 32 && a <= 512;   // tables through the bf16 MFMA kernel
+    w.core_t = big_a ? take((size_t)a * b * c * 2) : nullptr;
+    w.r_packed = big_a ? take(packed_bytes(RTK_BF16, n_u_max, a)) : nullptr;
     w.total = off;
     return w;
 }

@@ -46,6 +46,8 @@ struct RtkWorkspace {
     float *tables;        // n_u_max * b * c : M_u = G x_0 R[u]
     float *v;             // B * c fp32 query vectors
     void *q_packed;       // packed query planes
+    void *core_t;         // bf16, relation rank > 32: core transposed to [(b,c)][a]
+    void *r_packed;       // bf16, relation rank > 32: packed planes of the batch's relation rows
     size_t total;
 };
 

@@ -121,6 +121,47 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
     }
 }
 
+// ------------------------------------------- large relation rank, bf16 ------
+// For a > 32 the tables are a real GEMM, M[u, n] = sum_a R[u,a] * G[a,n] (n = (b,c) flattened).
+// It runs on the bf16 score kernel: the batch's relation rows play the queries (packed planes,
+// K = a) and the core, transposed to [(b,c)][a], plays the entity matrix -- both operands are
+// then K-contiguous, which is what the MFMA fragments want.
+__global__ __launch_bounds__(256) void transpose_core_kernel(const rtk_bf16 *__restrict__ G, int a, int64_t bc,
+                                                             rtk_bf16 *__restrict__ GT) {
+    __shared__ rtk_bf16 tile[64][66];
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int a0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+    for (int i = t; i < 64 * 64; i += 256) {      // rows of G (fixed a), 64 consecutive n: coalesced
+        const int ai = i >> 6, ni = i & 63;
+        rtk_bf16 x = 0;
+        if (a0 + ai < a && n0 + ni < bc) x = G[(int64_t)(a0 + ai) * bc + n0 + ni];
+        tile[ai][ni] = x;
+    }
+    __syncthreads();
+    for (int i = t; i < 64 * 64; i += 256) {      // rows of GT (fixed n), 64 consecutive a: coalesced
+        const int ni = i >> 6, ai = i & 63;
+        if (a0 + ai < a && n0 + ni < bc) GT[(n0 + ni) * a + a0 + ai] = tile[ai][ni];
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_rel_rows_kernel(const rtk_bf16 *__restrict__ R, int a, int n_rel,
+                                                            const int32_t *__restrict__ rel_list, int n_u_max,
+                                                            const uint32_t *__restrict__ n_u_dev,
+                                                            unsigned char *__restrict__ planes, int ksteps) {
+    const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
+    const int u = blockIdx.x;                      // one relation slot per block (rows >= n_u: zeros)
+    unsigned char *tile = planes + (int64_t)(u >> 5) * rtk_pack_tile_bytes(ksteps, 1);
+    const int row = u & 31;
+    if (threadIdx.x == 0) reinterpret_cast<float *>(tile)[row] = 1.0f;
+    rtk_bf16 *plane = reinterpret_cast<rtk_bf16 *>(tile + RTK_PACK_HDR);
+    int rel = 0;
+    if (u < n_u) rel = rel_list ? rel_list[u] : u;
+    rel = min(max(rel, 0), n_rel - 1);
+    for (int k = threadIdx.x; k < ksteps * 16; k += 256)
+        plane[rtk_pack_offset(ksteps, k, row)] = (u < n_u && k < a) ? R[(int64_t)rel * a + k] : (rtk_bf16)0;
+}
+
 // ------------------------------------------------------------ contract ------
 // One workgroup per query d:  v_d[c] = sum_b S[h_d, b] * M_slot[b, c].
 // 256 threads = G groups x (c/W) column slots; group g takes b = g, g+G, ...;
@@ -253,6 +294,17 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
         dim3 grid((unsigned)rtk_cdiv(bc, 256 * W), (unsigned)rtk_cdiv(n_u_max, UT));
         if (vec) hipLaunchKernelGGL((tables_kernel<T, true>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
         else hipLaunchKernelGGL((tables_kernel<T, false>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
+    } else if (sizeof(T) == 2 && ws.core_t && ws.r_packed) {
+        // bf16, a <= 512: transpose the core, pack the relation rows, run the bf16 MFMA score kernel
+        // with (queries, entities, K) := (relation slots, (b,c) pairs, a); raw fp32 output = the tables
+        const int ks_a = (a + 15) / 16;
+        dim3 tg((unsigned)rtk_cdiv(bc, 64), (unsigned)rtk_cdiv(a, 64));
+        hipLaunchKernelGGL(transpose_core_kernel, tg, dim3(256), 0, st, (const rtk_bf16 *)core, a, bc, (rtk_bf16 *)ws.core_t);
+        const int rows_padded = (int)rtk_cdiv(n_u_max, 32) * 32;
+        hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded), dim3(256), 0, st, (const rtk_bf16 *)R, a,
+                           (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)ws.r_packed, ks_a);
+        int rc = rtk_score_packed_bf16(ws.r_packed, n_u_max, a, ws.core_t, bc, ws.tables, bc, 0, (void *)st);
+        if (rc != RTK_OK) return rc;
     } else {
         // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM (bf16 operands widen on load)
         int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, ws.tables, bc, n_u_max, bc, a, 0, n_u_dev,
