@@ -39,6 +39,8 @@ WORKLOADS = {
     "wn18rr_asym_r10x200_b512_f32": (40943, 22, 512, (10, 200, 200), "f32"),
     # BASELINE.json configs[2] (parity-test case, selectable for measurements; not the default bench line)
     "fb15k237_sym_r200x200_b2048_bf16": (14541, 474, 2048, (200, 200, 200), "bf16"),
+    # one GPU's share of BASELINE.json configs[4] (1 M entities over 8 GPUs): shard-local measurement
+    "synthetic1m_shard125k_r256x512_b8192_bf16": (125000, 1000, 8192, (256, 512, 512), "bf16"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -107,7 +109,14 @@ def main():
     n_ent, n_rel, B, trank, dtype = WORKLOADS[args.workload]
     a, b, c = trank
     sym = "_sym_" in args.workload
-    core, R, S, O = [torch.from_numpy(x).to(dev) for x in gen.make_params(n_ent, n_rel, trank, 322, shared=sym)]
+    if n_ent * trank[1] > 50_000_000:      # big synthetic shapes: generate on the device
+        gd = torch.Generator(device=dev).manual_seed(322)
+        core = torch.randn(trank, generator=gd, device=dev) * (3.0 / float(np.sqrt(a * b * c)))
+        R = torch.randn((n_rel, a), generator=gd, device=dev)
+        S = torch.randn((n_ent, b), generator=gd, device=dev)
+        O = S if sym else torch.randn((n_ent, c), generator=gd, device=dev)
+    else:
+        core, R, S, O = [torch.from_numpy(x).to(dev) for x in gen.make_params(n_ent, n_rel, trank, 322, shared=sym)]
     bf16 = dtype == "bf16"
     if bf16:
         core, R, S, O = [x.to(torch.bfloat16) for x in (core, R, S, O)]

@@ -1,0 +1,110 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle needs
+seconds to minutes at these sizes, so only samples are evaluated exactly):
+
+* shard consistency -- the scores of a row block of O computed on their own are BIT-IDENTICAL to
+  the same columns of the full computation (every entity column is scaled, split and accumulated
+  independently of the others): this is what makes entity sharding (sharded.py) exact;
+* cross-implementation agreement -- the wave-specialised kernel, the two-workgroup kernel and
+  the exact-fp32 MFMA GEMM are three independent implementations of the same product;
+* sampled entries against the float64 oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen
+from oracle import score_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    assert torch.cuda.is_available()
+    import r_tucker_amd
+    r_tucker_amd._lib.load()
+    return r_tucker_amd
+
+
+def test_c2_wn18rr_full_size_properties(rt, monkeypatch):
+    n_ent, n_rel, B, rank = 40943, 22, 512, (10, 200, 200)
+    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 322)
+    h, r = gen.make_queries(n_ent, n_rel, B, 1234)
+    d = [torch.from_numpy(x).cuda() for x in (core, R, S, O)]
+    hh, rr = torch.from_numpy(h).cuda(), torch.from_numpy(r).cuda()
+    z = rt.score_1vN(*d, hh, rr, sigmoid=False)
+    # shard consistency, ragged 8-way split like bench.py --gpus 8
+    sh = rt.EntityShards(n_ent, 8)
+    for rank_id in (0, 3, 7):
+        lo, hi = sh.bounds(rank_id)
+        zs = rt.score_1vN(d[0], d[1], d[2], sh.take(d[3], rank_id), hh, rr, sigmoid=False)
+        assert torch.equal(zs[:, : hi - lo], z[:, lo:hi])
+    # three implementations
+    z_exact = rt.score_1vN(*d, hh, rr, sigmoid=False, exact=True)
+    err = ((z - z_exact).abs() / (1 + z_exact.abs())).max().item()
+    assert err <= 2e-5, err
+    # sampled entries vs float64
+    rng = np.random.default_rng(0)
+    qs, es = rng.choice(B, 48, replace=False), rng.choice(n_ent, 300, replace=False)
+    ze = orc.logits_exact(core, R, S, O[es], h[qs], r[qs])
+    zg = z[torch.from_numpy(qs).cuda()][:, torch.from_numpy(es).cuda()].cpu().numpy()
+    assert np.max(np.abs(zg - ze) / (1 + np.abs(ze))) <= 2e-5
+    # probabilities: monotone in the logits, in (0, 1], row sums match the logits' sigmoid
+    p = rt.score_1vN(*d, hh, rr)
+    assert float(p.min()) >= 0.0 and float(p.max()) <= 1.0
+    assert torch.allclose(p.double().sum(1), torch.sigmoid(z.double()).sum(1), rtol=1e-6)
+
+
+def test_c2_kernels_agree_v3_vs_ws():
+    """Same inputs through the two split-fp16 kernels (selected by RTK_SCORE_KERNEL at first use, so
+    the other one runs in a child process)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))
+import gen, r_tucker_amd as rt
+core, R, S, O = [torch.from_numpy(x).cuda() for x in gen.make_params(40943, 22, (10, 200, 200), 322)]
+h, r = [torch.from_numpy(x).cuda() for x in gen.make_queries(40943, 22, 512, 77)]
+z = rt.score_1vN(core, R, S, O, h, r, sigmoid=False)
+print(float(z.double().sum()), float(z.double().abs().sum()), float(z[17, 4093]), float(z[511, 40942]))
+'''
+    outs = []
+    for k in ("ws", "v3"):
+        env = dict(os.environ, RTK_SCORE_KERNEL=k)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append([float(x) for x in res.stdout.strip().split()[-4:]])
+    a, b = outs
+    assert abs(a[0] - b[0]) <= 1e-6 * a[1] and abs(a[2] - b[2]) <= 2e-5 * (1 + abs(a[2])) and abs(a[3] - b[3]) <= 2e-5 * (1 + abs(a[3]))
+
+
+def test_c5_shard_bf16_full_size_properties(rt):
+    """One GPU's share of BASELINE.json configs[4]: 125 000 of 1 M entities, rank (256,512,512),
+    batch 8192, bf16 (4.1 GB of fp32 scores)."""
+    n_loc, n_rel, B, rank = 125000, 1000, 8192, (256, 512, 512)
+    a, b, c = rank
+    g = torch.Generator(device="cuda").manual_seed(5)
+    core = (torch.randn(rank, generator=g, device="cuda") * (3.0 / np.sqrt(a * b * c))).bfloat16()
+    R = torch.randn((n_rel, a), generator=g, device="cuda").bfloat16()
+    S = torch.randn((n_loc, b), generator=g, device="cuda").bfloat16()     # subject lookups restricted to the shard's ids
+    O = torch.randn((n_loc, c), generator=g, device="cuda").bfloat16()
+    h = torch.randint(0, n_loc, (B,), generator=g, device="cuda")
+    r = torch.randint(0, n_rel, (B,), generator=g, device="cuda")
+    z = rt.score_1vN(core, R, S, O, h, r, sigmoid=False)
+    assert z.shape == (B, n_loc) and bool(torch.isfinite(z).all())
+    # shard consistency (bit-exact): a 3000-row sub-block
+    zs = rt.score_1vN(core, R, S, O[50000:53000].contiguous(), h, r, sigmoid=False)
+    assert torch.equal(zs, z[:, 50000:53000])
+    # sampled entries vs float64 of the same bf16 parameters
+    qs = torch.tensor([0, 1, 4095, 8191], device="cuda")
+    es = torch.tensor([0, 31, 64000, 124999], device="cuda")
+    ze = orc.logits_exact(core.float().cpu().numpy(), R.float().cpu().numpy(), S.float().cpu().numpy(),
+                          O[es].float().cpu().numpy(), h[qs].cpu().numpy(), r[qs].cpu().numpy())
+    zg = z[qs][:, es].cpu().numpy()
+    assert np.max(np.abs(zg - ze) / (1 + np.abs(ze))) <= 5e-2
+    del z, zs
+    torch.cuda.empty_cache()
