@@ -70,23 +70,9 @@ template <int KS, bool STAMP, unsigned XP, bool o_vec>
 __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict__ q_packed, unsigned char *stg,
                                        unsigned char *oreg, int lane, int w4, int ht) {
     constexpr int TILE_BYTES = tile_bytes<KS>();
-    constexpr int CHUNKS = TILE_BYTES / 16;
-    constexpr int NLD = (CHUNKS + 255) / 256;   // staging 16-B chunks per M thread
     constexpr int PF = KS < 3 ? KS : 3;         // A-fragment prefetch distance (k-steps): LDS latency > one k-step of MFMAs
     if (XP & 1) __builtin_amdgcn_s_setprio(3);
     const int r = lane & 31, h = lane >> 5, c = sc.c;
-    // The M waves also stage the query tiles (global -> registers at the top of an iteration,
-    // -> LDS in its last MFMA gaps): they issue no stores, so a staged load never queues behind
-    // a score store in the in-order vmcnt stream (the H waves' stores take ~1 us to retire).
-    u32x4 sreg[NLD];
-    // buffer loads: the tile base goes in the scalar offset, the per-thread part is a constant
-    // VGPR, chunks past the tile (last, partial round) fall outside num_records and read 0
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char *>(q_packed), 0, (unsigned)(sc.n_mt * TILE_BYTES), 0x00020000);
-    auto stage_load1 = [&](int mt, int i) {   // one 16-B chunk per thread (a 1-KiB wave instruction)
-        const unsigned vo = (i + 1 < NLD || i * 256 + ht < CHUNKS) ? (unsigned)(ht * 16) : 0x80000000u;
-        sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, mt * TILE_BYTES + i * 4096, 0);
-    };
     int ntile, mt0, cnt;
     bool more;
     while (sc.next(ntile, mt0, cnt, more)) {
@@ -176,11 +162,7 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
                 f32x16 acc, acc2;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = acc2[e] = 0.f;
-                const int mt_next = (i + 1 < cnt) ? mt0 + i + 1 : mt0 + i;   // (re)load something valid: branch-free
                 if (st) sp[3] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-                for (int li = 0; li < NLD; ++li) stage_load1(mt_next, li);   // tile i+1: all loads up front (L2 latency ~1k cycles)
-                u32x4 *sdst = reinterpret_cast<u32x4 *>(stg + ((i + 1) & 1) * TILE_BYTES);
                 f16x8 fa[PF], fl[PF];                // A fragments PF k-steps ahead
 #pragma unroll
                 for (int p = 0; p < PF; ++p) {
@@ -208,25 +190,13 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
                     __builtin_amdgcn_sched_barrier(0);
                     if ((3 * ks + 1) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc2, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc, 0, 0, 0);
-                    if (st && ks == KS - NLD) sp[4] = __builtin_amdgcn_s_memtime();
-                    if (ks >= KS - NLD && ks - (KS - NLD) < NLD) {   // staged tile i+1 -> LDS in the last gaps
-                        const int si = ks - (KS - NLD);
-                        const int ch = si * 256 + ht;
-                        if (si + 1 < NLD || ch < CHUNKS) sdst[ch] = sreg[si];
-                    }
+                    if (st && ks == KS / 2) sp[4] = __builtin_amdgcn_s_memtime();
                     __builtin_amdgcn_sched_barrier(0);
                     if ((3 * ks + 2) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc2, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (st) sp[5] = __builtin_amdgcn_s_memtime();
-                if (KS < NLD) {
-#pragma unroll
-                    for (int si = 0; si < NLD - (KS < NLD ? KS : NLD); ++si) {   // tiny ranks: leftovers after the chain
-                        const int ch = (si + KS) * 256 + ht;
-                        if (si + KS + 1 < NLD || ch < CHUNKS) sdst[ch] = sreg[si + KS];
-                    }
-                }
 #pragma unroll
                 for (int g = (KS < 4 ? KS : 4); g < 4; ++g) {
                     f32x4 z;
@@ -326,6 +296,11 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             const bool st = STAMP && i == 5 && lane == 0;
             unsigned long long *sp = g_ws_stamps + (blockIdx.x * 8 + 4 + w4) * 8;
             if (st) sp[0] = __builtin_amdgcn_s_memtime();
+            // Query tile i+1: its loads go out first -- in the in-order vmcnt stream they are OLDER than
+            // this iteration's score stores, so the wait at the bottom only covers stores issued a whole
+            // iteration ago -- and its LDS writes come last.
+            const bool stage = i + 1 < cnt;
+            if (stage) stage_load(mt0 + i + 1);
             if (i >= 2 && !(XP & 2)) {               // scores of tile i-2: logistic + stores
                 const int mt = mt0 + i - 2;
                 const f32x4 *exr = reinterpret_cast<const f32x4 *>(oreg + (i & 1) * EX_BYTES + w4 * 4096);
@@ -361,7 +336,9 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
                     off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
                 }
             }
-            if (st) sp[1] = sp[2] = sp[3] = __builtin_amdgcn_s_memtime();
+            if (st) sp[1] = __builtin_amdgcn_s_memtime();
+            if (stage) stage_store((i + 1) & 1);
+            if (st) sp[2] = sp[3] = __builtin_amdgcn_s_memtime();
             __syncthreads();
             if (st) sp[4] = __builtin_amdgcn_s_memtime();
         }
