@@ -21,8 +21,8 @@ void launch_v(const unsigned char *qp, int B, const float *O, int N, int c, floa
 template <int KS, int SG>
 void launch_one(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                 bool o_vec, hipStream_t st) {
-    if (o_vec) launch_v<KS, SG, true>(qp, B, O, N, c, out, ld, st);
-    else launch_v<KS, SG, false>(qp, B, O, N, c, out, ld, st);
+    launch_v<KS, SG, true>(qp, B, O, N, c, out, ld, st);   // the caller guarantees o_vec
+    (void)o_vec;
 }
 
 template <int KS>
@@ -39,6 +39,7 @@ void launch_ks(const unsigned char *qp, int B, const float *O, int N, int c, flo
 bool rtk_score_ws_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                          int sg, bool o_vec, hipStream_t st) {
     const int ks = (c + 15) / 16;
+    if (!o_vec) return false;   // c % 4 != 0 or unaligned O: the two-workgroup kernel has the scalar paths
 #define RTK_KS(K_) case K_: launch_ks<K_>(qp, B, O, N, c, out, ld, sg, o_vec, st); return true;
     switch (ks) {
         RTK_KS(1) RTK_KS(2) RTK_KS(3) RTK_KS(4) RTK_KS(5) RTK_KS(6) RTK_KS(7) RTK_KS(8) RTK_KS(9) RTK_KS(10)

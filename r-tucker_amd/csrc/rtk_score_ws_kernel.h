@@ -53,15 +53,46 @@ inline size_t lds_bytes(int c) {
 // they are separate functions so each gets its own register allocation (the M waves keep
 // 2*KS B fragments alive, the H waves a whole raw O tile).
 struct Sched {
+    // Work of one workgroup: first `base` WHOLE entity tiles (all query tiles each), then an even
+    // share of the remainder tiles' (entity tile, query tile) units.  With T tiles on W workgroups
+    // that is floor(T/W) full sweeps plus one partial sweep: at C2 (320 tiles, 256 CUs) every
+    // workgroup converts exactly 2 O tiles (an even cut of the whole linearised space gives 2.25 on
+    // average and up to 3, i.e. more O re-fetch and a longer critical path).
     int B, N, c, n_mt;
-    int64_t lin, lin_end;
-    __device__ __forceinline__ bool next(int &ntile, int &mt0, int &cnt, bool &more) {
-        if (lin >= lin_end) return false;
-        ntile = (int)(lin / n_mt);
-        mt0 = (int)(lin % n_mt);
-        cnt = (int)min((int64_t)(n_mt - mt0), lin_end - lin);
-        lin += cnt;
-        more = lin < lin_end;
+    int ta, ta_end;            // whole tiles [ta, ta_end)
+    int rem_tile0;             // first remainder tile
+    int lin, lin_end;          // remainder units, linearised (tile - rem_tile0) * n_mt + query tile
+    __device__ __forceinline__ void init(int B_, int N_, int c_, int w, int W) {
+        B = B_; N = N_; c = c_;
+        n_mt = (B + 31) / 32;
+        const int T = (N + 127) / 128;
+        const int base = T / W;
+        ta = w * base;
+        ta_end = ta + base;
+        rem_tile0 = base * W;
+        const int64_t Ur = (int64_t)(T - rem_tile0) * n_mt;
+        lin = (int)(Ur * w / W);
+        lin_end = (int)(Ur * (w + 1) / W);
+    }
+    __device__ __forceinline__ bool peek(int &tile) const {
+        if (ta < ta_end) { tile = ta; return true; }
+        if (lin < lin_end) { tile = rem_tile0 + lin / n_mt; return true; }
+        return false;
+    }
+    __device__ __forceinline__ bool next(int &ntile, int &mt0, int &cnt, bool &more, int &next_tile) {
+        if (ta < ta_end) {
+            ntile = ta++;
+            mt0 = 0;
+            cnt = n_mt;
+        } else if (lin < lin_end) {
+            ntile = rem_tile0 + lin / n_mt;
+            mt0 = lin % n_mt;
+            cnt = min(n_mt - mt0, lin_end - lin);
+            lin += cnt;
+        } else {
+            return false;
+        }
+        more = peek(next_tile);
         return true;
     }
 };
@@ -73,9 +104,9 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
     constexpr int PF = KS < 3 ? KS : 3;         // A-fragment prefetch distance (k-steps): LDS latency > one k-step of MFMAs
     if (XP & 1) __builtin_amdgcn_s_setprio(3);
     const int r = lane & 31, h = lane >> 5, c = sc.c;
-    int ntile, mt0, cnt;
+    int ntile, mt0, cnt, next_tile;
     bool more;
-    while (sc.next(ntile, mt0, cnt, more)) {
+    while (sc.next(ntile, mt0, cnt, more, next_tile)) {
         __syncthreads();                             // S1: raw O tile visible in LDS
         f16x8 Bh[KS], Bl[KS];
         float us_o;
@@ -238,7 +269,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
     constexpr int NOR = 2 * KS;                 // raw O 16-B pieces per helper thread (32*c/256 <= 2*KS)
     const int r = lane & 31, h = lane >> 5, c = sc.c, N = sc.N, B = sc.B;
     u32x4 oraw[NOR];
-    auto load_oraw = [&](int ntile) {   // 128 rows = 32*c pieces of 16 B, contiguous in memory
+    auto load_oraw = [&](int ntile) {   // 128 rows = 32*c pieces of 16 B, contiguous in memory (c % 4 == 0)
         const int64_t row0 = (int64_t)ntile * 128;
         const int valid = (int)max((int64_t)0, min((int64_t)128, (int64_t)N - row0)) * c;  // floats of real rows
         const float *src = O + row0 * c;
@@ -246,12 +277,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
         for (int i = 0; i < NOR; ++i) {
             const int pc = i * 256 + ht;
             u32x4 x = {0u, 0u, 0u, 0u};
-            if (pc < 32 * c) {
-                if (4 * pc + 4 <= valid) x = *reinterpret_cast<const u32x4 *>(src + 4 * pc);
-                else
-                    for (int q = 0; q < 4; ++q)
-                        if (4 * pc + q < valid) x[q] = __builtin_bit_cast(unsigned, src[4 * pc + q]);
-            }
+            if (4 * pc + 4 <= valid) x = *reinterpret_cast<const u32x4 *>(src + 4 * pc);   // valid % 4 == 0
             oraw[i] = x;
         }
     };
@@ -274,11 +300,14 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
     };
 
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-    load_oraw((int)(sc.lin / sc.n_mt));
+    {
+        int first_tile = 0;
+        if (sc.peek(first_tile)) load_oraw(first_tile);
+    }
     const unsigned ld4 = (unsigned)(ld_out * 4);
-    int ntile, mt0, cnt;
+    int ntile, mt0, cnt, next_tile;
     bool more;
-    while (sc.next(ntile, mt0, cnt, more)) {
+    while (sc.next(ntile, mt0, cnt, more, next_tile)) {
         const int j = ntile * 128 + w4 * 32 + r;     // entity: row of O, column of out
 #pragma unroll
         for (int i = 0; i < NOR; ++i) {
@@ -288,7 +317,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
         __syncthreads();                             // S1
         stage_load(mt0);                             // first query tile of the sweep (the M waves are busy converting)
         stage_store(0);
-        if (more) load_oraw(ntile + 1);              // stays in registers for the whole sweep
+        if (more) load_oraw(next_tile);              // stays in registers for the whole sweep
         __syncthreads();                             // S2
         if (STAMP && lane == 0 && g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
@@ -357,11 +386,7 @@ __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     unsigned char *const oreg = lds + 2 * tile_bytes<KS>();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     Sched sc;
-    sc.B = B; sc.N = N; sc.c = c;
-    sc.n_mt = (B + 31) / 32;
-    const int64_t U = (int64_t)((N + 127) / 128) * sc.n_mt;
-    sc.lin = U * blockIdx.x / gridDim.x;
-    sc.lin_end = U * (blockIdx.x + 1) / gridDim.x;
+    sc.init(B, N, c, blockIdx.x, gridDim.x);
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
     if (__builtin_amdgcn_readfirstlane(wave) < 4) m_role<KS, STAMP, XP, O_VEC>(sc, q_packed, stg, oreg, lane, wave & 3, t & 255);
     else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, wave & 3, t & 255);
