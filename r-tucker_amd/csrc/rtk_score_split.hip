@@ -55,15 +55,20 @@ void launch_ks(const unsigned char *qp, int B, const float *O, int N, int c, flo
 
 bool rtk_score_ws_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                          int sg, bool o_vec, hipStream_t st);
+bool rtk_score_ws2_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
+                          int sg, bool o_vec, hipStream_t st);
 
-// RTK_SCORE_KERNEL=v3 forces the two-workgroups-per-CU kernel (A/B comparisons)
-static bool use_ws_kernel() {
+// Default: the persistent wave-specialised kernel (ws), then the two-workgroups-per-CU kernel (v3)
+// for the shapes ws does not cover.  RTK_SCORE_KERNEL=v3 forces v3; =ws2 tries the two-tiles-per-
+// barrier variant first (A/B comparisons: measured slower than ws at the WN18RR shape, 53.9 vs
+// 48.5 us -- its helper waves' store bursts stall longer, tools/ablate/run_ws2.py).
+static int kernel_choice() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("RTK_SCORE_KERNEL");
-        v = (e && e[0] == 'v' && e[1] == '3') ? 0 : 1;
+        v = (e && e[0] == 'v' && e[1] == '3') ? 0 : (e && e[0] == 'w' && e[1] == 's' && e[2] == '2') ? 2 : 1;
     }
-    return v == 1;
+    return v;
 }
 
 int rtk_split_ksteps_supported(int c) {
@@ -86,7 +91,9 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
     const bool o_vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
     const int B = (int)batch, N = (int)n_local;
     const unsigned char *qp = (const unsigned char *)q_packed;
-    if (use_ws_kernel() && rtk_score_ws_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st))
+    if (kernel_choice() >= 2 && rtk_score_ws2_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st))
+        return rtk_check_launch("rtk_score_packed_f32");
+    if (kernel_choice() >= 1 && rtk_score_ws_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st))
         return rtk_check_launch("rtk_score_packed_f32");
     // the packed planes were written for exactly `ks` k-steps (tile stride), so the
     // instantiation must match exactly.

@@ -62,3 +62,24 @@ extern "C" int rtk_ablate_ws_stamps(unsigned long long *host, int n, int clear) 
     }
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rtk_ws::g_ws_stamps), sizeof(unsigned long long) * n);
 }
+
+// ---- two-tiles-per-barrier kernel (rtk_score_ws2_kernel.h), STAMP build
+#include "rtk_score_ws2_kernel.h"
+extern "C" int rtk_ablate_ws2(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld,
+                              int grid, void *stream) {
+    if ((c + 15) / 16 != 13) return -3;
+    const size_t smem = rtk_ws2::lds_bytes<13>(c);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws2::score_ws2_kernel<13, 2, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((rtk_ws2::score_ws2_kernel<13, 2, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream,
+                       (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld);
+    return (int)hipGetLastError();
+}
+extern "C" int rtk_ablate_ws2_stamps(unsigned long long *host, int n, int clear) {
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(rtk_ws2::g_ws2_stamps)) != hipSuccess) return -1;
+        return (int)hipMemset(p, 0, sizeof(unsigned long long) * 256 * 8 * rtk_ws2::STAMPS_PER_WAVE);
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rtk_ws2::g_ws2_stamps), sizeof(unsigned long long) * n);
+}
