@@ -51,6 +51,9 @@ static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, i
     const bool big_a = dtype == RTK_BF16 && a > 32 && a <= 512;   // tables through the bf16 MFMA kernel
     w.core_t = big_a ? take((size_t)a * b * c * 2) : nullptr;
     w.r_packed = big_a ? take(packed_bytes(RTK_BF16, n_u_max, a)) : nullptr;
+    w.grp_cnt = (int32_t *)take((size_t)n_u_max * 8);
+    w.grp_order = (int32_t *)take((size_t)batch * 4);
+    w.grp_work = (int32_t *)take((size_t)(batch / 4 + n_u_max + 1) * 16);
     w.total = off;
     return w;
 }

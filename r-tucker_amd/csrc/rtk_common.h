@@ -48,6 +48,9 @@ struct RtkWorkspace {
     void *q_packed;       // packed query planes
     void *core_t;         // bf16, relation rank > 32: core transposed to [(b,c)][a]
     void *r_packed;       // bf16, relation rank > 32: packed planes of the batch's relation rows
+    int32_t *grp_cnt;     // 2 * n_u_max : queries per table slot; scatter cursor
+    int32_t *grp_order;   // B : query ids sorted by table slot
+    int32_t *grp_work;    // 4 * (B / 4 + n_u_max) : contract work items (slot, first, count, -)
     size_t total;
 };
 

@@ -10,6 +10,7 @@
 // planes" the split-fp16 score kernel consumes (per-row power-of-two scaling and
 // hi/lo fp16 split in MFMA-fragment order; layout in rtk_pack.h).
 #include "rtk_common.h"
+#include <stdlib.h>
 #include "rtk_pack.h"
 
 namespace {
@@ -45,6 +46,85 @@ __global__ __launch_bounds__(1024) void plan_kernel(const int64_t *__restrict__ 
     if (t == 0) flags[1] = count;
 }
 
+// -------------------------------------------------------------- groups ------
+// Queries bucketed by table slot, for the grouped contract kernel: order[] = query ids sorted by
+// slot, work[w] = (slot, first position in order[], count <= QG), flags[2] = number of work items.
+// Runs on ONE workgroup of 256 threads -- as an extra block of the kernel that builds the tables,
+// so it costs no launch.  The order inside a slot is arbitrary (atomic tickets); every query's
+// row is computed independently, so the result does not depend on it.
+constexpr int GROUPS_LDS_SLOTS = 2048;   // counters live in LDS up to this many slots (global atomics beyond)
+__device__ void build_groups(const int64_t *__restrict__ rel_idx, int B, int n_rel,
+                             const int32_t *__restrict__ slot_of_rel, int n_slots, int QG,
+                             int32_t *__restrict__ cnt_g, int32_t *__restrict__ order,
+                             int32_t *__restrict__ work, uint32_t *__restrict__ flags) {
+    __shared__ int sc_q[256], sc_w[256];
+    __shared__ int base_q, base_w;
+    __shared__ int cnt_l[2 * GROUPS_LDS_SLOTS];
+    const int t = threadIdx.x;
+    // one code path: the counters are either the LDS array or the workspace array (generic pointers)
+    int *cnt = n_slots <= GROUPS_LDS_SLOTS ? cnt_l : cnt_g;
+    int *fill = cnt + n_slots;
+    for (int s = t; s < 2 * n_slots; s += 256) cnt[s] = 0;
+    if (t == 0) { base_q = 0; base_w = 0; }
+    __syncthreads();
+    for (int d = t; d < B; d += 256) {
+        int64_t r = rel_idx[d];
+        r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);   // bad ids are reported by the contract kernel
+        const int s = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+        atomicAdd(&cnt[s], 1);
+    }
+    __syncthreads();
+    // exclusive scans (queries, work items) over the slots, 256 at a time; fill[] := first position
+    for (int s0 = 0; s0 < n_slots; s0 += 256) {
+        const int s = s0 + t;
+        const int nq = s < n_slots ? cnt[s] : 0;
+        const int nw = (nq + QG - 1) / QG;
+        sc_q[t] = nq;
+        sc_w[t] = nw;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int aq = t >= o ? sc_q[t - o] : 0, aw = t >= o ? sc_w[t - o] : 0;
+            __syncthreads();
+            sc_q[t] += aq;
+            sc_w[t] += aw;
+            __syncthreads();
+        }
+        const int q0 = base_q + sc_q[t] - nq, w0 = base_w + sc_w[t] - nw;
+        if (s < n_slots) {
+            fill[s] = q0;
+            for (int k = 0; k < nw; ++k) {
+                int32_t *wk = work + 4 * (int64_t)(w0 + k);
+                wk[0] = s;
+                wk[1] = q0 + k * QG;
+                wk[2] = min(QG, nq - k * QG);
+                wk[3] = 0;
+            }
+        }
+        __syncthreads();
+        if (t == 255) { base_q += sc_q[255]; base_w += sc_w[255]; }
+        __syncthreads();
+    }
+    if (t == 0) flags[2] = (uint32_t)base_w;
+    for (int d = t; d < B; d += 256) {
+        int64_t r = rel_idx[d];
+        r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);
+        const int s = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+        order[atomicAdd(&fill[s], 1)] = d;
+    }
+}
+
+struct GroupArgs {   // by value to the kernels that host the extra block
+    const int64_t *rel_idx;
+    const int32_t *slot_of_rel;
+    int32_t *cnt, *order, *work;
+    uint32_t *flags;
+    int B, n_rel, n_slots, QG;
+};
+
+__global__ __launch_bounds__(256) void groups_kernel(GroupArgs ga) {
+    build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags);
+}
+
 // -------------------------------------------------------------- tables ------
 // M[u, n] = sum_a R[rel(u), a] * G[a, n],  n in [0, b*c).  Streaming VALU kernel for
 // small relation rank (a <= 32: WN18RR has a = 10): each thread owns one float4 of
@@ -55,8 +135,12 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
                                                      const T *__restrict__ R,
                                                      const int32_t *__restrict__ rel_list, int n_u_max,
                                                      const uint32_t *__restrict__ n_u_dev,
-                                                     float *__restrict__ M) {
+                                                     float *__restrict__ M, GroupArgs ga) {
     __shared__ float Rs[UT * 64];  // UT relations x a (a <= 64 here)
+    if (ga.QG > 0 && blockIdx.x == gridDim.x - 1) {   // the extra block: query groups for the contract kernel
+        if (blockIdx.y == 0) build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags);
+        return;
+    }
     const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
     const int u0 = blockIdx.y * UT;
     if (u0 >= n_u) return;
@@ -79,23 +163,25 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
     for (int u = 0; u < UT; ++u)
 #pragma unroll
         for (int j = 0; j < W; ++j) acc[u][j] = 0.f;
-    // the loads of 8 consecutive relation-rank slices are issued together (independent of the
-    // FMAs): with one load per trip the kernel is a chain of `a` exposed L2 latencies
-    for (int a0 = 0; a0 < a; a0 += 8) {
-        float g[8][W];
+    // the loads of up to 16 consecutive relation-rank slices are issued together (independent of
+    // the FMAs): with one load per trip the kernel is a chain of `a` exposed L2 latencies
+    constexpr int AB = 16;
+    for (int a0 = 0; a0 < a; a0 += AB) {
+        float g[AB][W];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ai = min(a0 + k, a - 1);
-            if (VEC) {
-                const f32x4 x = rtk_load4(G + (int64_t)ai * bc + n);
+        for (int k = 0; k < AB; ++k) {
+            if (a0 + k < a) {   // wave-uniform: the loads of a batch still issue back to back
+                if (VEC) {
+                    const f32x4 x = rtk_load4(G + (int64_t)(a0 + k) * bc + n);
 #pragma unroll
-                for (int j = 0; j < W; ++j) g[k][j] = x[j];
-            } else {
-                g[k][0] = rtk_to_f32(G[(int64_t)ai * bc + n]);
+                    for (int j = 0; j < W; ++j) g[k][j] = x[j];
+                } else {
+                    g[k][0] = rtk_to_f32(G[(int64_t)(a0 + k) * bc + n]);
+                }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < AB; ++k) {
             if (a0 + k < a) {
 #pragma unroll
                 for (int u = 0; u < UT; ++u) {
@@ -148,7 +234,12 @@ __global__ __launch_bounds__(256) void transpose_core_kernel(const rtk_bf16 *__r
 __global__ __launch_bounds__(256) void pack_rel_rows_kernel(const rtk_bf16 *__restrict__ R, int a, int n_rel,
                                                             const int32_t *__restrict__ rel_list, int n_u_max,
                                                             const uint32_t *__restrict__ n_u_dev,
-                                                            unsigned char *__restrict__ planes, int ksteps) {
+                                                            unsigned char *__restrict__ planes, int ksteps,
+                                                            GroupArgs ga) {
+    if (ga.QG > 0 && blockIdx.x == gridDim.x - 1) {   // the extra block: query groups for the contract kernel
+        build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags);
+        return;
+    }
     const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
     const int u = blockIdx.x;                      // one relation slot per block (rows >= n_u: zeros)
     unsigned char *tile = planes + (int64_t)(u >> 5) * rtk_pack_tile_bytes(ksteps, 1);
@@ -166,7 +257,7 @@ __global__ __launch_bounds__(256) void pack_rel_rows_kernel(const rtk_bf16 *__re
 // One workgroup per query d:  v_d[c] = sum_b S[h_d, b] * M_slot[b, c].
 // 256 threads = G groups x (c/W) column slots; group g takes b = g, g+G, ...;
 // partial sums meet in LDS.  The finished row is written as fp32 and/or packed.
-template <typename T, bool VEC>
+template <typename T, bool VEC, int LB = 8>
 __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__ M, int b, int c,
                                                        const T *__restrict__ S, int64_t n_sub,
                                                        const int64_t *__restrict__ rel_idx,
@@ -174,13 +265,24 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ slot_of_rel,
                                                        float *__restrict__ v_out,
                                                        unsigned char *__restrict__ q_packed, int ksteps,
-                                                       uint32_t *__restrict__ flags) {
+                                                       uint32_t *__restrict__ flags,
+                                                       const int32_t *__restrict__ order, int B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_row = smem;                      // b floats
     float *part = smem + ((b + 3) & ~3);      // G * cpad floats, later the finished row
     __shared__ float red[4];
     constexpr int W = VEC ? 4 : 1;
-    const int d = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
+    int d = blockIdx.x;
+    if (order) {
+        // Workgroups go round-robin to the 8 XCDs; XCD x takes the x-th eighth of the queries in
+        // slot order, so its L2 serves a few tables instead of all of them.
+        const int n8 = (B + 7) / 8, pos = (blockIdx.x & 7) * n8 + (blockIdx.x >> 3);
+        if (pos >= B) return;
+        d = order[pos];
+    } else if (d >= B) {
+        return;
+    }
     const int cols = (c + W - 1) / W;         // column slots
     const int cpad = cols * W;
     const int ngroups = max(1, 256 / cols);   // groups of b
@@ -206,15 +308,31 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
         for (int j = 0; j < W; ++j) acc[j] = 0.f;
         if (active) {
             const int gstep = (npass == 1) ? ngroups : 1;
-#pragma unroll 8
-            for (int bi = g; bi < b; bi += gstep) {
-                const float sv = s_row[bi];
-                if (VEC) {
-                    const f32x4 x = *reinterpret_cast<const f32x4 *>(Mq + (int64_t)bi * c + col * 4);
+            // LB table rows are requested before the first one is used: with one load per trip the
+            // thread walks a chain of b/gstep exposed L2 latencies (the whole kernel is that chain)
+            for (int b0 = g; b0 < b; b0 += gstep * LB) {
+                float x[LB][W];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(sv, x[j], acc[j]);
-                } else {
-                    acc[0] = fmaf(sv, Mq[(int64_t)bi * c + col], acc[0]);
+                for (int k = 0; k < LB; ++k) {
+                    const int bi = b0 + k * gstep;
+                    if (bi < b) {
+                        if (VEC) {
+                            const f32x4 y = *reinterpret_cast<const f32x4 *>(Mq + (int64_t)bi * c + col * 4);
+#pragma unroll
+                            for (int j = 0; j < W; ++j) x[k][j] = y[j];
+                        } else {
+                            x[k][0] = Mq[(int64_t)bi * c + col];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    const int bi = b0 + k * gstep;
+                    if (bi < b) {
+                        const float sv = s_row[bi];
+#pragma unroll
+                        for (int j = 0; j < W; ++j) acc[j] = fmaf(sv, x[k][j], acc[j]);
+                    }
                 }
             }
 #pragma unroll
@@ -264,6 +382,160 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
     }
 }
 
+// ---------------------------------------------------- grouped contract ------
+// One workgroup per work item = up to QG queries that share a table slot: every table row is
+// loaded once for the QG queries (the per-query kernel above re-reads the whole table for each
+// query -- B * b * c * 4 bytes through the L2, the bound of that kernel).
+//     v_d[c] = sum_b S[h_d, b] * M_slot[b, c]        d in the group
+// 256 threads = G groups of b x (c/W) column slots, partial sums meet in LDS; the finished rows
+// go out as fp32 and/or packed planes exactly as in the per-query kernel.
+template <typename T, bool VEC, int QG>
+__global__ __launch_bounds__(256) void contract_grouped_kernel(
+    const float *__restrict__ M, int b, int c, const T *__restrict__ S, int64_t n_sub,
+    const int64_t *__restrict__ rel_idx, const int64_t *__restrict__ sub_idx, int n_rel,
+    const int32_t *__restrict__ work, const int32_t *__restrict__ order, float *__restrict__ v_out,
+    unsigned char *__restrict__ q_packed, int ksteps, uint32_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[4][QG];
+    __shared__ int qid[QG];
+    constexpr int W = VEC ? 4 : 1;
+    const int t = threadIdx.x;
+    // work items are in slot order; XCD x (workgroups go round-robin to the 8 XCDs) takes the x-th
+    // eighth of them, so a table is read through one L2
+    const int n_work = (int)flags[2], n8 = (n_work + 7) / 8;
+    const int item = (blockIdx.x & 7) * n8 + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= n8 || item >= n_work) return;
+    const int32_t *wk = work + 4 * (int64_t)item;
+    const int slot = wk[0], q0 = wk[1], nq = wk[2];
+    const int bpad = (b + 3) & ~3;
+    const int cols = (c + W - 1) / W, cpad = cols * W;   // cols <= 256 (host)
+    const int ngroups = 256 / cols;
+    float *s_rows = smem;                    // QG x bpad
+    float *part = smem + QG * bpad;          // QG x ngroups x cpad, later the finished rows
+    const float *Mq = M + (int64_t)slot * b * c;
+
+    if (t < QG) {
+        int d = -1;
+        if (t < nq) {
+            d = order[q0 + t];
+            const int64_t h = sub_idx[d], r = rel_idx[d];
+            if (h < 0 || h >= n_sub || r < 0 || r >= n_rel) atomicOr(&flags[0], 1u);
+        }
+        qid[t] = d;
+    }
+    __syncthreads();
+    for (int i = t; i < QG * b; i += 256) {
+        const int q = i / b, bi = i - q * b;
+        float x = 0.f;
+        if (q < nq) {
+            int64_t h = sub_idx[qid[q]];
+            h = h < 0 || h >= n_sub ? 0 : h;
+            x = rtk_to_f32(S[h * b + bi]);
+        }
+        s_rows[q * bpad + bi] = x;
+    }
+    __syncthreads();
+
+    const int g = t / cols, col = t - g * cols;
+    if (g < ngroups) {
+        float acc[QG][W];
+#pragma unroll
+        for (int q = 0; q < QG; ++q)
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[q][j] = 0.f;
+        constexpr int LB = QG <= 4 ? 20 : 8;  // table rows requested before the first is used (bytes in flight set the rate)
+        for (int b0 = g; b0 < b; b0 += ngroups * LB) {
+            float x[LB][W];
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const int bi = b0 + k * ngroups;
+                if (bi < b) {
+                    if (VEC) {
+                        const f32x4 y = *reinterpret_cast<const f32x4 *>(Mq + (int64_t)bi * c + col * 4);
+#pragma unroll
+                        for (int j = 0; j < W; ++j) x[k][j] = y[j];
+                    } else {
+                        x[k][0] = Mq[(int64_t)bi * c + col];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const int bi = b0 + k * ngroups;
+                if (bi < b) {
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) {
+                        const float sv = s_rows[q * bpad + bi];
+#pragma unroll
+                        for (int j = 0; j < W; ++j) acc[q][j] = fmaf(sv, x[k][j], acc[q][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QG; ++q)
+#pragma unroll
+            for (int j = 0; j < W; ++j) part[(q * ngroups + g) * cpad + col * W + j] = acc[q][j];
+    }
+    __syncthreads();
+    // reduce the groups in group order (the per-query kernel's summation order); thread k owns column k
+    float mx[QG];
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+        mx[q] = 0.f;
+        if (q < nq) {
+            for (int k = t; k < c; k += 256) {
+                float x = 0.f;
+                for (int gg = 0; gg < ngroups; ++gg) x += part[(q * ngroups + gg) * cpad + k];
+                part[q * ngroups * cpad + k] = x;
+                mx[q] = fmaxf(mx[q], fabsf(x));
+                if (v_out) v_out[(int64_t)qid[q] * c + k] = x;
+            }
+        }
+    }
+    if (!q_packed) return;
+    if (sizeof(T) == 2) {   // bf16: one plane, round to nearest even, no scaling
+        __syncthreads();
+        for (int q = 0; q < nq; ++q) {
+            const int d = qid[q];
+            unsigned char *tile = q_packed + (int64_t)(d >> 5) * rtk_pack_tile_bytes(ksteps, 1);
+            const int row = d & 31;
+            if (t == 0) reinterpret_cast<float *>(tile)[row] = 1.0f;
+            rtk_bf16 *plane = reinterpret_cast<rtk_bf16 *>(tile + RTK_PACK_HDR);
+            const float *rowv = part + q * ngroups * cpad;
+            for (int k = t; k < ksteps * 16; k += 256)
+                plane[rtk_pack_offset(ksteps, k, row)] = rtk_f32_to_bf16((k < c) ? rowv[k] : 0.f);
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o));
+        if ((t & 63) == 0) red[t >> 6][q] = mx[q];
+    }
+    __syncthreads();
+    for (int q = 0; q < nq; ++q) {
+        const float m = fmaxf(fmaxf(red[0][q], red[1][q]), fmaxf(red[2][q], red[3][q]));
+        const int sh = rtk_pack_shift(m);
+        const float up = ldexpf(1.0f, sh);
+        const int d = qid[q];
+        unsigned char *tile = q_packed + (int64_t)(d >> 5) * rtk_pack_tile_bytes(ksteps, 2);
+        const int row = d & 31;
+        if (t == 0) reinterpret_cast<float *>(tile)[row] = ldexpf(1.0f, -sh);
+        _Float16 *planes = reinterpret_cast<_Float16 *>(tile + RTK_PACK_HDR);
+        const float *rowv = part + q * ngroups * cpad;
+        for (int k = t; k < ksteps * 16; k += 256) {
+            const float x = (k < c) ? rowv[k] * up : 0.f;
+            const _Float16 hi = (_Float16)x;
+            const _Float16 lo = (_Float16)(x - (float)hi);
+            const int off = rtk_pack_offset(ksteps, k, row);
+            planes[off] = hi;
+            planes[off + ksteps * 512] = lo;
+        }
+    }
+}
+
 }  // namespace
 
 int rtk_gemm_f32_ex(const void *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const void *B,
@@ -288,12 +560,29 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
     const int32_t *rel_list = planned ? ws.rel_list : nullptr;
     const uint32_t *n_u_dev = planned ? ws.flags + 1 : nullptr;
     constexpr int VA = rtk_vec4_align<T>();
+    // contract kernel: grouped by table slot when its tile fits (QG queries share every table row)
+    const bool cvec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws.tables) & 15) == 0);
+    const int cW = cvec ? 4 : 1;
+    const int ccols = (c + cW - 1) / cW;
+    const int QG = batch >= 2048 ? 8 : 4;
+    const size_t smem_grouped = ccols <= 256
+        ? (size_t)((size_t)QG * ((b + 3) & ~3) + (size_t)QG * (256 / ccols) * ccols * cW) * sizeof(float) : (size_t)-1;
+    static const int force = [] {   // RTK_CONTRACT=perquery|grouped: A/B comparisons
+        const char *e = getenv("RTK_CONTRACT");
+        return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'g' ? 2 : 0));
+    }();
+    const bool grouped = smem_grouped <= 64 * 1024 && force != 1 && (batch >= 2048 || force == 2);
+    // the slot order is built either way: the per-query kernel uses it to keep a table in one XCD's L2
+    const bool build = batch < (1ll << 31);
+    GroupArgs ga{rel_idx, planned ? ws.slot_of_rel : nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
+                 (int)batch, (int)n_rel, n_u_max, build ? QG : 0};
+    const unsigned xb = build ? 1u : 0u;   // the extra block that builds the groups
     if (a <= 32) {
         const bool vec = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(core) & (VA - 1)) == 0);
         const int W = vec ? 4 : 1;
-        dim3 grid((unsigned)rtk_cdiv(bc, 256 * W), (unsigned)rtk_cdiv(n_u_max, UT));
-        if (vec) hipLaunchKernelGGL((tables_kernel<T, true>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
-        else hipLaunchKernelGGL((tables_kernel<T, false>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables);
+        dim3 grid((unsigned)rtk_cdiv(bc, 256 * W) + xb, (unsigned)rtk_cdiv(n_u_max, UT));
+        if (vec) hipLaunchKernelGGL((tables_kernel<T, true>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables, ga);
+        else hipLaunchKernelGGL((tables_kernel<T, false>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables, ga);
     } else if (sizeof(T) == 2 && ws.core_t && ws.r_packed) {
         // bf16, a <= 512: transpose the core, pack the relation rows, run the bf16 MFMA score kernel
         // with (queries, entities, K) := (relation slots, (b,c) pairs, a); raw fp32 output = the tables
@@ -301,15 +590,25 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
         dim3 tg((unsigned)rtk_cdiv(bc, 64), (unsigned)rtk_cdiv(a, 64));
         hipLaunchKernelGGL(transpose_core_kernel, tg, dim3(256), 0, st, (const rtk_bf16 *)core, a, bc, (rtk_bf16 *)ws.core_t);
         const int rows_padded = (int)rtk_cdiv(n_u_max, 32) * 32;
-        hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded), dim3(256), 0, st, (const rtk_bf16 *)R, a,
-                           (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)ws.r_packed, ks_a);
+        hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded + xb), dim3(256), 0, st, (const rtk_bf16 *)R, a,
+                           (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)ws.r_packed, ks_a, ga);
         int rc = rtk_score_packed_bf16(ws.r_packed, n_u_max, a, ws.core_t, bc, ws.tables, bc, 0, (void *)st);
         if (rc != RTK_OK) return rc;
     } else {
         // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM (bf16 operands widen on load)
+        if (build) hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(256), 0, st, ga);
         int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, ws.tables, bc, n_u_max, bc, a, 0, n_u_dev,
                                  sizeof(T) == 2, st);
         if (rc != RTK_OK) return rc;
+    }
+    const int ksteps_g = (c + 15) / 16;
+    if (grouped) {
+        const unsigned nwg = (unsigned)(batch / QG + n_u_max + 8);   // upper bound on the work items, rounded up to 8 (flags[2] holds the count)
+#define RTK_CG(V_, Q_) hipLaunchKernelGGL((contract_grouped_kernel<T, V_, Q_>), dim3(nwg), dim3(256), smem_grouped, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, ws.grp_work, ws.grp_order, v_out, (unsigned char *)q_packed, ksteps_g, ws.flags)
+        if (cvec) { if (QG == 8) RTK_CG(true, 8); else RTK_CG(true, 4); }
+        else { if (QG == 8) RTK_CG(false, 8); else RTK_CG(false, 4); }
+#undef RTK_CG
+        return rtk_check_launch("rtk_query_vectors");
     }
     const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws.tables) & 15) == 0);
     const int W = vec ? 4 : 1;
@@ -318,8 +617,10 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
     const size_t smem = (size_t)(((b + 3) & ~3) + (size_t)ngroups * cols * W) * sizeof(float);
     RTK_REQUIRE(smem <= 64 * 1024, RTK_ERR_UNSUPPORTED, "rtk_query_vectors: rank too large for the contract kernel (b=%d c=%d)", b, c);
     const int ksteps = (c + 15) / 16;
-    if (vec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
-    else hipLaunchKernelGGL((contract_kernel<T, false>), dim3((unsigned)batch), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags);
+    const int32_t *pq_order = build ? ws.grp_order : nullptr;
+    const unsigned pq_grid = (unsigned)(build ? rtk_cdiv(batch, 8) * 8 : batch);
+    if (vec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3(pq_grid), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags, pq_order, (int)batch);
+    else hipLaunchKernelGGL((contract_kernel<T, false>), dim3(pq_grid), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags, pq_order, (int)batch);
     return rtk_check_launch("rtk_query_vectors");
 }
 
