@@ -132,7 +132,11 @@ def main():
     O_loc = torch.zeros((n_loc, c), dtype=O.dtype, device=dev)
     O_loc[: hi - lo] = O[lo:hi]                       # last shard zero-padded to equal size
     # rank p's (B, n_loc) block is slot p of the gather buffer: the kernel writes its block in place
-    gathered = torch.empty((world, B, n_loc), dtype=torch.float32, device=dev)
+    # row pitch of the score block: rows start on 128-byte boundaries (r_tucker_amd.ops.ROW_ALIGN,
+    # the layout score_1vN allocates; R_TUCKER_AMD_ROW_ALIGN=1 gives the dense (B, n_loc) layout)
+    ra = _ops.ROW_ALIGN
+    pitch = -(-n_loc // ra) * ra
+    gathered = torch.empty((world, B, pitch), dtype=torch.float32, device=dev)
     out = gathered[rank]
 
     stream = torch.cuda.current_stream(dev)
@@ -154,10 +158,10 @@ def main():
         if ev:
             ev[0].record(stream)
         if args.exact:
-            _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
+            _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch,
                                          _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
         else:
-            _lib.check(sp_fn(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), n_loc,
+            _lib.check(sp_fn(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch,
                                                 sflags, sp), "rtk_score_packed_f32")
         if ev:
             ev[1].record(stream)
@@ -208,7 +212,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": args.workload, "entities": n_ent, "relations": n_rel, "rank": list(trank),
-                   "batch": B, "scores_per_query": n_ent,
+                   "batch": B, "scores_per_query": n_ent, "score_row_pitch": pitch,
                    "score_kernel": "exact_f32_mfma" if args.exact else ("bf16_mfma" if bf16 else "split_fp16_mfma"),
                    "sigmoid": "exact" if args.exact else sig_mode,
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
@@ -221,7 +225,7 @@ def main():
     if world > 1:
         # the exchange step: every rank receives (P-1) blocks of B*n_loc fp32 over xGMI
         # (7 links x ~153 GB/s per GPU, MI355X guide); reported next to the shard-local rate
-        recv = (world - 1) * B * n_loc * 4
+        recv = (world - 1) * B * pitch * 4
         result["exchange"] = {"collective": "all_gather_into_tensor (RCCL, in place)", "ms": gather_ms,
                               "bytes_received_per_gpu": recv, "achieved_GBps": recv / (gather_ms * 1e-3) / 1e9,
                               "xgmi_peak_GBps": 7 * 153.0, "frac": recv / (gather_ms * 1e-3) / 1e9 / (7 * 153.0),

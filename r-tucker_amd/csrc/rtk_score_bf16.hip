@@ -10,6 +10,7 @@
 // of the previous tile in the MFMA gaps.  With a third of the MFMA work of the fp32 path the
 // kernel is bound by the fp32 score write (HBM).
 #include "rtk_common.h"
+#include <stdlib.h>
 #include "rtk_pack.h"
 
 namespace {
@@ -22,29 +23,36 @@ __device__ __forceinline__ float logistic_fast(float z) {
     return fmaf(p, fmaf(-d, p, 1.0f), p);
 }
 
-template <int KS, int SIGMOID, int MINW>
-__global__ __launch_bounds__(256, MINW) void score_bf16_kernel(
+// NW waves per workgroup, 32 entity rows each: the staged query tile is shared by 32*NW entities,
+// so its L2 -> CU traffic per score is 2*K / (32*NW) bytes (K = 512, NW = 4: 8 B per 4-B score).
+// QB = query tiles per block of the sweep: every workgroup walks the query blocks in the same
+// order, so the chip works on one block (QB tiles, <= ~1.5 MB) at a time and it stays in the L2s.
+template <int KS, int SIGMOID, int MINW, int NW, bool NTS>
+__global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
     const unsigned char *__restrict__ q_packed, int B, const rtk_bf16 *__restrict__ O, int N, int c,
-    float *__restrict__ out, int64_t ld_out, bool o_vec) {
+    float *__restrict__ out, int64_t ld_out, bool o_vec, int QB) {
     constexpr int TILE_BYTES = RTK_PACK_HDR + KS * 1024;
     constexpr int CHUNKS = TILE_BYTES / 16;
-    constexpr int NLD = (CHUNKS + 255) / 256;
+    constexpr int NT = 64 * NW;               // threads
+    constexpr int NLD = (CHUNKS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * TILE_BYTES
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int n_mt = (B + 31) / 32;
-    const int64_t U = (int64_t)((N + 127) / 128) * n_mt;
-    int64_t lin = U * blockIdx.x / gridDim.x;
-    const int64_t lin_end = U * (blockIdx.x + 1) / gridDim.x;
+    const int n_mt = (B + 31) / 32, n_nt = (N + 32 * NW - 1) / (32 * NW);
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(q_packed), 0, (unsigned)(n_mt * TILE_BYTES), 0x00020000);
 
+    for (int qb0 = 0; qb0 < n_mt; qb0 += QB) {
+    const int tq = min(QB, n_mt - qb0);       // query tiles of this block
+    const int64_t U = (int64_t)n_nt * tq;
+    int64_t lin = U * blockIdx.x / gridDim.x;
+    const int64_t lin_end = U * (blockIdx.x + 1) / gridDim.x;
     while (lin < lin_end) {
-        const int ntile = (int)(lin / n_mt), mt0 = (int)(lin % n_mt);
-        const int cnt = (int)min((int64_t)(n_mt - mt0), lin_end - lin);
+        const int ntile = (int)(lin / tq), mt0 = qb0 + (int)(lin % tq);
+        const int cnt = (int)min((int64_t)(qb0 + tq - mt0), lin_end - lin);
         lin += cnt;
-        const int j = ntile * 128 + wave * 32 + r;  // entity (row of O, column of out)
+        const int j = ntile * 32 * NW + wave * 32 + r;  // entity (row of O, column of out)
 
         // B fragments: lane (r, h) holds k = 16*ks + 8*h + q, q < 8 of row j = 16 contiguous bytes
         const rtk_bf16 *orow = O + (int64_t)min(j, N - 1) * c;
@@ -67,15 +75,15 @@ __global__ __launch_bounds__(256, MINW) void score_bf16_kernel(
         auto stage_load = [&](int mt) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const unsigned vo = (i + 1 < NLD || i * 256 + t < CHUNKS) ? (unsigned)(t * 16) : 0x80000000u;
-                stg[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, mt * TILE_BYTES + i * 4096, 0);
+                const unsigned vo = (i + 1 < NLD || i * NT + t < CHUNKS) ? (unsigned)(t * 16) : 0x80000000u;
+                stg[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, mt * TILE_BYTES + i * NT * 16, 0);
             }
         };
         auto stage_store = [&](int buf) {
             u32x4 *dst = reinterpret_cast<u32x4 *>(lds + buf * TILE_BYTES);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int ch = i * 256 + t;
+                const int ch = i * NT + t;
                 if (i + 1 < NLD || ch < CHUNKS) dst[ch] = stg[i];
             }
         };
@@ -107,7 +115,8 @@ __global__ __launch_bounds__(256, MINW) void score_bf16_kernel(
                 float pv = ep_p;
                 if (SIGMOID == 2) pv = fmaf(ep_p, fmaf(-ep_d, ep_p, 1.0f), ep_p);
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, 0);
+                // NTS (128-B aligned rows): nontemporal -- the scores are written once and not re-read here
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, NTS ? 2 : 0);
                 ep_off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
             }
         };
@@ -150,29 +159,54 @@ __global__ __launch_bounds__(256, MINW) void score_bf16_kernel(
 #pragma unroll
         for (int pc = 0; pc < 32; ++pc) piece(prev, pc);
     }
+    }
 }
 
-template <int KS, int SG, int MINW>
-void launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
+template <int KS, int SG, int MINW, int NW, bool NTS>
+void launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
                 hipStream_t st) {
-    constexpr size_t smem = 2 * (size_t)(RTK_PACK_HDR + KS * 1024);
+    constexpr size_t tile = RTK_PACK_HDR + KS * 1024, smem = 2 * tile;
     static bool attr_set = false;
     if (smem > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW, NW, NTS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    const int64_t units = rtk_cdiv(N, 128) * rtk_cdiv(B, 32);
+    const int n_mt = (int)rtk_cdiv(B, 32);
+    int qb = (int)((3 << 19) / tile);          // query tiles per block of the sweep: <= 1.5 MB of packed planes
+    if (qb >= n_mt) qb = n_mt;
+    else qb = (int)rtk_cdiv(n_mt, rtk_cdiv(n_mt, qb));   // equal blocks
+    const int64_t units = rtk_cdiv(N, 32 * NW) * (int64_t)qb;
     const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
-    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW>), dim3(grid), dim3(256), smem, st, qp, B, O, N, c, out, ld, o_vec);
+    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW, NW, NTS>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
+}
+
+template <int KS, int SG, int MINW, int NW>
+void launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
+                hipStream_t st) {
+    static const bool nts_off = getenv("RTK_NO_NT_STORES") != nullptr;
+    const bool nts = !nts_off && (ld * 4) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
+    if constexpr (SG != 1) {   // (the exact-logistic variant keeps one form)
+        if (nts) return launch_nt<KS, SG, MINW, NW, true>(qp, B, O, N, c, out, ld, o_vec, st);
+    }
+    launch_nt<KS, SG, MINW, NW, false>(qp, B, O, N, c, out, ld, o_vec, st);
+}
+
+template <int KS, int MINW, int NW>
+void launch_ks(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, int sg,
+               bool o_vec, hipStream_t st) {
+    if (sg == 0) launch_one<KS, 0, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, st);
+    else if (sg == 1) launch_one<KS, 1, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, st);
+    else launch_one<KS, 2, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, st);
 }
 
 template <int KS, int MINW>
-void launch_ks(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, int sg,
-               bool o_vec, hipStream_t st) {
-    if (sg == 0) launch_one<KS, 0, MINW>(qp, B, O, N, c, out, ld, o_vec, st);
-    else if (sg == 1) launch_one<KS, 1, MINW>(qp, B, O, N, c, out, ld, o_vec, st);
-    else launch_one<KS, 2, MINW>(qp, B, O, N, c, out, ld, o_vec, st);
+void launch_shape(bool wide, const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld,
+                  int sg, bool o_vec, hipStream_t st) {
+    if constexpr (KS > 16) {
+        if (wide) return launch_ks<KS, 1, 8>(qp, B, O, N, c, out, ld, sg, o_vec, st);
+    }
+    launch_ks<KS, MINW, 4>(qp, B, O, N, c, out, ld, sg, o_vec, st);
 }
 
 }  // namespace
@@ -192,7 +226,9 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
     const unsigned char *qp = (const unsigned char *)q_packed;
     const rtk_bf16 *Ob = (const rtk_bf16 *)O;
     const int B = (int)batch, N = (int)n_local;
-#define RTK_KS(K_, W_) case K_: launch_ks<K_, W_>(qp, B, Ob, N, c, out, ld_out, sg, o_vec, st); break;
+    // 8-wave workgroups (256 entities share a staged query tile) once the problem fills the chip that way
+    const bool wide = ks > 16 && rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256;
+#define RTK_KS(K_, W_) case K_: launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, st); break;
     switch (ks) {
         RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
         RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)

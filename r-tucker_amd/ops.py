@@ -25,6 +25,21 @@ _workspaces = {}
 # (<= ~2 ulp, ~3x fewer VALU instructions).  Override with R_TUCKER_AMD_SIGMOID.
 DEFAULT_SIGMOID = os.environ.get("R_TUCKER_AMD_SIGMOID", "fast")
 
+# Row pitch of a freshly allocated score matrix, in elements.  Rows that start on a 128-byte
+# boundary are written in full lines (and, in the bf16 kernel, with nontemporal stores): measured
+# 5-20 % of the score kernel (tools/ubench/vmem_rate.hip).  With N not a
+# multiple of the pitch unit the result is the (B, N) view of a (B, pitch) buffer, i.e. NOT
+# contiguous; R_TUCKER_AMD_ROW_ALIGN=1 restores the dense layout.  The autograd path (training)
+# always uses the dense layout.
+ROW_ALIGN = max(1, int(os.environ.get("R_TUCKER_AMD_ROW_ALIGN", "32")))
+
+
+def alloc_scores(B, N, device, lead=()):
+    """(lead..., B, N) float32 score buffer whose rows start on ROW_ALIGN-element boundaries."""
+    pitch = -(-N // ROW_ALIGN) * ROW_ALIGN
+    buf = torch.empty(tuple(lead) + (B, pitch), dtype=torch.float32, device=device)
+    return buf[..., :N] if pitch != N else buf
+
 
 def _require_gpu(name, t):
     if not isinstance(t, torch.Tensor):
@@ -95,7 +110,7 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
         # asymmetric/R_TuckER.py:46: .view(-1, b) of a (B,1,c) tensor
         raise RuntimeError(f"shape '[-1, {b}]' is invalid for input of size {B * c}")
     if out is None:
-        out = torch.empty((B, N), dtype=torch.float32, device=dev)
+        out = torch.empty((B, N), dtype=torch.float32, device=dev) if want_v else alloc_scores(B, N, dev)
     elif (tuple(out.shape) != (B, N) or out.dtype != torch.float32 or out.device != dev or out.stride(1) != 1
           or out.stride(0) < N):
         raise RuntimeError(f"out must be a float32 ({B}, {N}) tensor on {dev} with unit column stride")

@@ -65,7 +65,10 @@ class ShardedEntityScorer:
         return self.shards.take(full_entity_matrix, self.rank)
 
     def _buffer(self, B, device, dtype):
-        need = (self.world, B, self.shards.n_loc)
+        # rows start on ROW_ALIGN-element boundaries (ops.alloc_scores): the storage is (P, B, pitch)
+        from .ops import ROW_ALIGN
+        pitch = -(-self.shards.n_loc // ROW_ALIGN) * ROW_ALIGN
+        need = (self.world, B, pitch)
         g = self._gathered
         if g is None or tuple(g.shape) != need or g.device != device or g.dtype != dtype:
             g = torch.empty(need, dtype=dtype, device=device)
@@ -76,13 +79,14 @@ class ShardedEntityScorer:
         """All ranks' score blocks, ``(P, B, n_loc)``; slot p = rank p's entities.
         Columns past the real entity count in the last shard are padding (sigmoid(0) = 0.5)."""
         B = int(subject_idx.numel())
-        g = self._buffer(B, core.device, core.dtype)
-        mine = g[self.rank]                                   # (B, n_loc) view: the kernel writes in place
+        g = self._buffer(B, core.device, torch.float32)      # the score kernels write fp32 for either operand type
+        n_loc = self.shards.n_loc
+        mine = g[self.rank][:, :n_loc]                        # (B, n_loc) view: the kernel writes in place
         self.local_score(core, R, S, O_loc, subject_idx, relation_idx, out=mine, **kw)
         if self.world > 1:
-            # in-place all-gather: input is the rank-th slice of the output buffer
-            dist.all_gather_into_tensor(g.view(-1), mine.view(-1), group=self.group)
-        return g
+            # in-place all-gather of the padded storage: input is the rank-th slice of the output buffer
+            dist.all_gather_into_tensor(g.view(-1), g[self.rank].view(-1), group=self.group)
+        return g[:, :, :n_loc]
 
     def view_BPn(self, gathered: torch.Tensor) -> torch.Tensor:
         """(B, P, n_loc) view of the gathered buffer: [d, p, i] = score of entity p*n_loc + i."""
