@@ -53,8 +53,9 @@ typedef enum rtk_dtype {
 #define RTK_SCORE_SIGMOID 1u      /* apply sigmoid (R_TuckER.py:48); else raw logits  */
 #define RTK_SCORE_EXACT_F32 2u    /* fp32 operands: force the exact-fp32 MFMA kernel   */
                                   /* instead of the split-fp16 (hi/lo) MFMA kernel     */
-#define RTK_SCORE_SIGMOID_FAST 4u /* with RTK_SCORE_SIGMOID: v_exp_f32/v_rcp_f32 + one  */
-                                  /* Newton step instead of expf + IEEE divide           */
+#define RTK_SCORE_SIGMOID_FAST 4u /* with RTK_SCORE_SIGMOID: 1 / (1 + 2^(-z log2 e)) on  */
+                                  /* v_exp_f32 + v_rcp_f32 (1 ulp each) instead of expf */
+                                  /* + IEEE divide                                      */
 
 int rtk_version(void);
 const char *rtk_last_error_string(void);

@@ -15,14 +15,6 @@
 
 namespace {
 
-__device__ __forceinline__ float logistic_fast(float z) {
-    const float t = fminf(z * -1.4426950408889634f, 126.0f);
-    const float e = __builtin_amdgcn_exp2f(t);
-    const float d = 1.0f + e;
-    const float p = __builtin_amdgcn_rcpf(d);
-    return fmaf(p, fmaf(-d, p, 1.0f), p);
-}
-
 // NW waves per workgroup, 32 entity rows each: the staged query tile is shared by 32*NW entities,
 // so its L2 -> CU traffic per score is 2*K / (32*NW) bytes (K = 512, NW = 4: 8 B per 4-B score).
 // QB = query tiles per block of the sweep: every workgroup walks the query blocks in the same
@@ -103,9 +95,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
             const int e = pc >> 1;
             if ((pc & 1) == 0) {
                 if (SIGMOID == 2) {
-                    const float tt = fminf(z[e] * -1.4426950408889634f, 126.0f);
-                    ep_d = 1.0f + __builtin_amdgcn_exp2f(tt);
-                    ep_p = __builtin_amdgcn_rcpf(ep_d);
+                    ep_d = __builtin_amdgcn_exp2f(z[e] * -1.4426950408889634f);   // 2^t = inf for very negative z: p = 0
                 } else if (SIGMOID == 1) {
                     ep_d = 1.0f + expf(-z[e]);
                 } else {
@@ -113,7 +103,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
                 }
             } else {
                 float pv = ep_p;
-                if (SIGMOID == 2) pv = fmaf(ep_p, fmaf(-ep_d, ep_p, 1.0f), ep_p);
+                if (SIGMOID == 2) pv = __builtin_amdgcn_rcpf(1.0f + ep_d);   // v_exp_f32 / v_rcp_f32 are 1-ulp
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
                 // NTS (128-B aligned rows): nontemporal -- the scores are written once and not re-read here
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, NTS ? 2 : 0);

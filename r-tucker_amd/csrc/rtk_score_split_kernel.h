@@ -11,16 +11,7 @@ __device__ unsigned long long g_stamps[4096 * 4];
 __device__ unsigned long long g_istamps[4096 * 8];   // ABL bit 7: s_memtime stamps inside iteration 3
 
 // SIGMOID: 0 = raw logits, 1 = ocml expf + IEEE divide (torch-CPU formula, ~25 VALU),
-//          2 = v_exp_f32 / v_rcp_f32 + one Newton step (7 VALU, <= ~2 ulp for z >= 0)
-__device__ __forceinline__ float logistic_fast(float z) {
-    const float t = fminf(z * -1.4426950408889634f, 126.0f);  // exp2 argument; clamp keeps 1+e finite
-    const float e = __builtin_amdgcn_exp2f(t);
-    const float d = 1.0f + e;
-    const float p = __builtin_amdgcn_rcpf(d);
-    const float rr = fmaf(-d, p, 1.0f);
-    return fmaf(p, rr, p);
-}
-
+//          2 = 1 / (1 + 2^(-z log2 e)) on v_exp_f32 + v_rcp_f32 (4 VALU, 1 ulp each)
 template <int KS, int SIGMOID, int MINW, unsigned ABL = 0>
 __global__ __launch_bounds__(256, MINW) void score_split_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
@@ -151,9 +142,7 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
             const int e = pc >> 1;
             if ((pc & 1) == 0) {
                 if (SIGMOID == 2) {
-                    const float tt = fminf(z[e] * -1.4426950408889634f, 126.0f);
-                    ep_d = 1.0f + __builtin_amdgcn_exp2f(tt);
-                    ep_p = __builtin_amdgcn_rcpf(ep_d);
+                    ep_d = __builtin_amdgcn_exp2f(z[e] * -1.4426950408889634f);   // 2^t = inf for very negative z: p = 0
                 } else if (SIGMOID == 1) {
                     ep_d = 1.0f + expf(-z[e]);
                 } else {
@@ -161,7 +150,7 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 }
             } else {
                 float pv = ep_p;
-                if (SIGMOID == 2) pv = fmaf(ep_p, fmaf(-ep_d, ep_p, 1.0f), ep_p);
+                if (SIGMOID == 2) pv = __builtin_amdgcn_rcpf(1.0f + ep_d);   // v_exp_f32 / v_rcp_f32 are 1-ulp
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
                 const int row = (e & 3) + 8 * (e >> 2);  // + 4*h inside voff
                 if (off(4)) {

@@ -26,14 +26,6 @@
 
 namespace rtk_ws {
 
-__device__ __forceinline__ float logistic_fast(float z) {
-    const float t = fminf(z * -1.4426950408889634f, 126.0f);  // exp2 argument; clamp keeps 1+e finite
-    const float e = __builtin_amdgcn_exp2f(t);
-    const float d = 1.0f + e;
-    const float p = __builtin_amdgcn_rcpf(d);
-    return fmaf(p, fmaf(-d, p, 1.0f), p);
-}
-
 // tools/ablate only: cycle stamps (STAMP template flag)
 __device__ unsigned long long g_ws_stamps[256 * 8 * 8];
 

@@ -21,8 +21,8 @@ from . import _lib
 _workspaces = {}
 
 # Logistic used by the fused score epilogue: "exact" = expf + IEEE divide (the formula
-# torch's CPU kernel evaluates), "fast" = v_exp_f32 / v_rcp_f32 + one Newton step
-# (<= ~2 ulp, ~3x fewer VALU instructions).  Override with R_TUCKER_AMD_SIGMOID.
+# torch's CPU kernel evaluates), "fast" = 1 / (1 + 2^(-z log2 e)) on v_exp_f32 + v_rcp_f32
+# (1 ulp each; ~6x fewer VALU instructions).  Override with R_TUCKER_AMD_SIGMOID.
 DEFAULT_SIGMOID = os.environ.get("R_TUCKER_AMD_SIGMOID", "fast")
 
 # Row pitch of a freshly allocated score matrix, in elements.  Rows that start on a 128-byte
