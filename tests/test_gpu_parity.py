@@ -135,6 +135,33 @@ def test_ragged_shapes_against_oracle(rt, shape, exact):
     assert np.max(np.abs(v - ve)) <= 2e-5 * (1 + np.abs(ve).max())
 
 
+@pytest.mark.parametrize("shape", [
+    # batch >= 2048 -> contract grouped by table slot (<= 8 queries share every table row)
+    (700, 37, 2500, (6, 48, 48)),        # ~68 queries per relation: full and ragged groups
+    (300, 3000, 2100, (40, 24, 24)),     # n_rel > batch: planned slots, most groups hold one query
+    (513, 5, 2049, (4, 7, 7)),           # c % 4 != 0: scalar load path
+])
+def test_grouped_contract_rows_equal_per_query_rows(rt, shape):
+    """The grouped contract kernel (large batches) must produce, row for row, the bits the
+    one-workgroup-per-query kernel produces (same summation order), and match the oracle."""
+    n_ent, n_rel, B, rank = shape
+    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 23)
+    h, r = gen.make_queries(n_ent, n_rel, B, 23)
+    cd, Rd, Sd = dev(core, R, S)
+    hd, rd = dev(h, r)
+    v_grouped = rt.query_vectors(cd, Rd, Sd, hd, rd)
+    assert v_grouped.shape == (B, rank[2])
+    pieces = [rt.query_vectors(cd, Rd, Sd, hd[i:i + 1000].contiguous(), rd[i:i + 1000].contiguous())
+              for i in range(0, B, 1000)]                        # batches < 2048: per-query kernel
+    assert torch.equal(v_grouped, torch.cat(pieces))
+    ve = orc.query_vectors_exact(core, R, S, h, r)
+    assert np.max(np.abs(v_grouped.cpu().numpy() - ve)) <= 2e-5 * (1 + np.abs(ve).max())
+    # and through the packed planes into the score kernel
+    z = rt.score_1vN(*dev(core, R, S, O, h, r), sigmoid=False).cpu().numpy()
+    assert zerr(z, orc.logits_exact(core, R, S, O, h, r)) <= Z_TOL
+    rt.check_device_errors()
+
+
 def test_wide_dynamic_range_rows(rt):
     """Per-row power-of-two scaling of the split-fp16 path: rows of O and S spanning
     30 orders of magnitude must not lose accuracy or overflow."""
