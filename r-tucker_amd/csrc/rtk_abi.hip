@@ -54,6 +54,7 @@ static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, i
     w.grp_cnt = (int32_t *)take((size_t)n_u_max * 8);
     w.grp_order = (int32_t *)take((size_t)batch * 4);
     w.grp_work = (int32_t *)take((size_t)(batch / 4 + n_u_max + 1) * 16);
+    w.grp_qinfo = (int64_t *)take((size_t)batch * 16);
     w.total = off;
     return w;
 }

@@ -51,6 +51,7 @@ struct RtkWorkspace {
     int32_t *grp_cnt;     // 2 * n_u_max : queries per table slot; scatter cursor
     int32_t *grp_order;   // B : query ids sorted by table slot
     int32_t *grp_work;    // 4 * (B / 4 + n_u_max) : contract work items (slot, first, count, -)
+    int64_t *grp_qinfo;   // 2 * B : per position in slot order (subject id, query id | slot << 32)
     size_t total;
 };
 

@@ -56,7 +56,8 @@ constexpr int GROUPS_LDS_SLOTS = 2048;   // counters live in LDS up to this many
 __device__ void build_groups(const int64_t *__restrict__ rel_idx, int B, int n_rel,
                              const int32_t *__restrict__ slot_of_rel, int n_slots, int QG,
                              int32_t *__restrict__ cnt_g, int32_t *__restrict__ order,
-                             int32_t *__restrict__ work, uint32_t *__restrict__ flags) {
+                             int32_t *__restrict__ work, uint32_t *__restrict__ flags,
+                             const int64_t *__restrict__ sub_idx, int64_t *__restrict__ qinfo) {
     __shared__ int sc_q[256], sc_w[256];
     __shared__ int base_q, base_w;
     __shared__ int cnt_l[2 * GROUPS_LDS_SLOTS];
@@ -109,7 +110,12 @@ __device__ void build_groups(const int64_t *__restrict__ rel_idx, int B, int n_r
         int64_t r = rel_idx[d];
         r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);
         const int s = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
-        order[atomicAdd(&fill[s], 1)] = d;
+        const int pos = atomicAdd(&fill[s], 1);
+        order[pos] = d;
+        if (qinfo) {   // what the per-query contract kernel needs about position pos, in one 16-B load
+            qinfo[2 * (int64_t)pos] = sub_idx[d];
+            qinfo[2 * (int64_t)pos + 1] = (int64_t)(uint32_t)d | ((int64_t)s << 32);
+        }
     }
 }
 
@@ -119,10 +125,12 @@ struct GroupArgs {   // by value to the kernels that host the extra block
     int32_t *cnt, *order, *work;
     uint32_t *flags;
     int B, n_rel, n_slots, QG;
+    const int64_t *sub_idx;
+    int64_t *qinfo;
 };
 
 __global__ __launch_bounds__(256) void groups_kernel(GroupArgs ga) {
-    build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags);
+    build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
 }
 
 // -------------------------------------------------------------- tables ------
@@ -138,13 +146,36 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
                                                      float *__restrict__ M, GroupArgs ga) {
     __shared__ float Rs[UT * 64];  // UT relations x a (a <= 64 here)
     if (ga.QG > 0 && blockIdx.x == gridDim.x - 1) {   // the extra block: query groups for the contract kernel
-        if (blockIdx.y == 0) build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags);
+        if (blockIdx.y == 0) build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
         return;
     }
     const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
     const int u0 = blockIdx.y * UT;
     if (u0 >= n_u) return;
     const int t = threadIdx.x;
+    constexpr int W = VEC ? 4 : 1;
+    constexpr int AB = 16;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + t) * W;
+    const bool live = n < bc;
+    // the first AB relation-rank slices of G are requested before anything else: they do not depend
+    // on the R rows, whose trip through LDS (load, store, barrier) would otherwise sit in front of
+    // them as one more exposed latency of this short kernel
+    float g[AB][W];
+    auto load_slices = [&](int a0) {
+#pragma unroll
+        for (int k = 0; k < AB; ++k) {
+            if (live && a0 + k < a) {   // wave-uniform in k: the loads of a batch still issue back to back
+                if (VEC) {
+                    const f32x4 x = rtk_load4(G + (int64_t)(a0 + k) * bc + n);
+#pragma unroll
+                    for (int j = 0; j < W; ++j) g[k][j] = x[j];
+                } else {
+                    g[k][0] = rtk_to_f32(G[(int64_t)(a0 + k) * bc + n]);
+                }
+            }
+        }
+    };
+    load_slices(0);
     for (int i = t; i < UT * a; i += 256) {
         const int u = u0 + i / a, ai = i % a;
         float x = 0.f;
@@ -155,31 +186,14 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
         Rs[(i / a) * 64 + ai] = x;
     }
     __syncthreads();
-    constexpr int W = VEC ? 4 : 1;
-    const int64_t n = ((int64_t)blockIdx.x * 256 + t) * W;
-    if (n >= bc) return;
+    if (!live) return;
     float acc[UT][W];
 #pragma unroll
     for (int u = 0; u < UT; ++u)
 #pragma unroll
         for (int j = 0; j < W; ++j) acc[u][j] = 0.f;
-    // the loads of up to 16 consecutive relation-rank slices are issued together (independent of
-    // the FMAs): with one load per trip the kernel is a chain of `a` exposed L2 latencies
-    constexpr int AB = 16;
     for (int a0 = 0; a0 < a; a0 += AB) {
-        float g[AB][W];
-#pragma unroll
-        for (int k = 0; k < AB; ++k) {
-            if (a0 + k < a) {   // wave-uniform: the loads of a batch still issue back to back
-                if (VEC) {
-                    const f32x4 x = rtk_load4(G + (int64_t)(a0 + k) * bc + n);
-#pragma unroll
-                    for (int j = 0; j < W; ++j) g[k][j] = x[j];
-                } else {
-                    g[k][0] = rtk_to_f32(G[(int64_t)(a0 + k) * bc + n]);
-                }
-            }
-        }
+        if (a0 > 0) load_slices(a0);
 #pragma unroll
         for (int k = 0; k < AB; ++k) {
             if (a0 + k < a) {
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256) void pack_rel_rows_kernel(const rtk_bf16 *__re
                                                             unsigned char *__restrict__ planes, int ksteps,
                                                             GroupArgs ga) {
     if (ga.QG > 0 && blockIdx.x == gridDim.x - 1) {   // the extra block: query groups for the contract kernel
-        build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags);
+        build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
         return;
     }
     const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
@@ -266,38 +280,45 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
                                                        float *__restrict__ v_out,
                                                        unsigned char *__restrict__ q_packed, int ksteps,
                                                        uint32_t *__restrict__ flags,
-                                                       const int32_t *__restrict__ order, int B) {
+                                                       const int64_t *__restrict__ qinfo, int B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *s_row = smem;                      // b floats
-    float *part = smem + ((b + 3) & ~3);      // G * cpad floats, later the finished row
+    float *part = smem;                       // G * cpad floats, later the finished row
     __shared__ float red[4];
     constexpr int W = VEC ? 4 : 1;
     const int t = threadIdx.x;
     int d = blockIdx.x;
-    if (order) {
+    int64_t h, r = 0;
+    int slot = -1;
+    if (qinfo) {
         // Workgroups go round-robin to the 8 XCDs; XCD x takes the x-th eighth of the queries in
-        // slot order, so its L2 serves a few tables instead of all of them.
+        // slot order, so its L2 serves a few tables instead of all of them.  (subject, query, slot)
+        // of that position come in one 16-B load (build_groups).
         const int n8 = (B + 7) / 8, pos = (blockIdx.x & 7) * n8 + (blockIdx.x >> 3);
         if (pos >= B) return;
-        d = order[pos];
-    } else if (d >= B) {
-        return;
+        h = qinfo[2 * (int64_t)pos];
+        const int64_t ds = qinfo[2 * (int64_t)pos + 1];
+        d = (int)(uint32_t)ds;
+        slot = (int)(ds >> 32);
+        r = rel_idx[d];                       // only to report a bad id (the slot is already clamped)
+    } else {
+        if (d >= B) return;
+        h = sub_idx[d];
+        r = rel_idx[d];
     }
     const int cols = (c + W - 1) / W;         // column slots
     const int cpad = cols * W;
     const int ngroups = max(1, 256 / cols);   // groups of b
     const int npass = (cols + 255) / 256;     // > 1 only when cols > 256
 
-    int64_t h = sub_idx[d], r = rel_idx[d];
     bool bad = false;
     if (h < 0 || h >= n_sub) { bad = true; h = 0; }
     if (r < 0 || r >= n_rel) { bad = true; r = 0; }
     if (bad && t == 0) atomicOr(&flags[0], 1u);
-    const int slot = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+    if (slot < 0) slot = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
     const float *Mq = M + (int64_t)slot * b * c;
-
-    for (int i = t; i < b; i += 256) s_row[i] = rtk_to_f32(S[h * b + i]);
-    __syncthreads();
+    const T *Sh = S + h * b;                  // this query's subject row: read straight from memory
+                                              // (group-uniform addresses), not staged through LDS --
+                                              // the table loads then do not wait behind a barrier
 
     for (int pass = 0; pass < npass; ++pass) {
         const int g = (npass == 1) ? t / cols : 0;
@@ -311,11 +332,12 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
             // LB table rows are requested before the first one is used: with one load per trip the
             // thread walks a chain of b/gstep exposed L2 latencies (the whole kernel is that chain)
             for (int b0 = g; b0 < b; b0 += gstep * LB) {
-                float x[LB][W];
+                float x[LB][W], sx[LB];
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
                     const int bi = b0 + k * gstep;
                     if (bi < b) {
+                        sx[k] = rtk_to_f32(Sh[bi]);
                         if (VEC) {
                             const f32x4 y = *reinterpret_cast<const f32x4 *>(Mq + (int64_t)bi * c + col * 4);
 #pragma unroll
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
                 for (int k = 0; k < LB; ++k) {
                     const int bi = b0 + k * gstep;
                     if (bi < b) {
-                        const float sv = s_row[bi];
+                        const float sv = sx[k];
 #pragma unroll
                         for (int j = 0; j < W; ++j) acc[j] = fmaf(sv, x[k][j], acc[j]);
                     }
@@ -575,7 +597,7 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
     // the slot order is built either way: the per-query kernel uses it to keep a table in one XCD's L2
     const bool build = batch < (1ll << 31);
     GroupArgs ga{rel_idx, planned ? ws.slot_of_rel : nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
-                 (int)batch, (int)n_rel, n_u_max, build ? QG : 0};
+                 (int)batch, (int)n_rel, n_u_max, build ? QG : 0, sub_idx, ws.grp_qinfo};
     const unsigned xb = build ? 1u : 0u;   // the extra block that builds the groups
     if (a <= 32) {
         const bool vec = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(core) & (VA - 1)) == 0);
@@ -614,10 +636,10 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
     const int W = vec ? 4 : 1;
     const int cols = (c + W - 1) / W;
     const int ngroups = cols >= 256 ? 1 : 256 / cols;
-    const size_t smem = (size_t)(((b + 3) & ~3) + (size_t)ngroups * cols * W) * sizeof(float);
+    const size_t smem = (size_t)ngroups * cols * W * sizeof(float);
     RTK_REQUIRE(smem <= 64 * 1024, RTK_ERR_UNSUPPORTED, "rtk_query_vectors: rank too large for the contract kernel (b=%d c=%d)", b, c);
     const int ksteps = (c + 15) / 16;
-    const int32_t *pq_order = build ? ws.grp_order : nullptr;
+    const int64_t *pq_order = build ? ws.grp_qinfo : nullptr;
     const unsigned pq_grid = (unsigned)(build ? rtk_cdiv(batch, 8) * 8 : batch);
     if (vec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3(pq_grid), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags, pq_order, (int)batch);
     else hipLaunchKernelGGL((contract_kernel<T, false>), dim3(pq_grid), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags, pq_order, (int)batch);
