@@ -181,6 +181,24 @@ int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t 
                           const int64_t *pair_ptr, const int64_t *pair_obj,
                           int32_t *ranks_out, double *bce_rows_out, void *stream);
 
+/*
+ * The same ranking with the entity dimension sharded over GPUs (no gather of the scores): a rank
+ * holds columns [col0, col0 + n_local) of the score matrix; the count is a sum over columns.
+ *   1. rtk_target_scores_f32: pt_out[d] = P[d, obj_idx[d] - col0] where this rank owns the queried
+ *      object, -inf elsewhere;  all-reduce MAX over the ranks gives every rank the target scores;
+ *   2. rtk_filtered_rank_partial_f32: counts_out[d] = this block's share of
+ *      #{j: p'_j > p_t} + #{j < t: p'_j == p_t}  (obj_idx and pair_obj hold GLOBAL entity ids), and
+ *      optionally its share of the row's BCE sum;  all-reduce SUM, then rank = 1 + count.
+ * B x 12 bytes cross the links instead of B x N x 4 (train.py:113-117 on a sharded entity matrix).
+ */
+int rtk_target_scores_f32(const float *P, int64_t batch, int64_t n_local, int64_t ld, int64_t col0,
+                          const int64_t *obj_idx, float *pt_out, void *stream);
+
+int rtk_filtered_rank_partial_f32(const float *P, int64_t batch, int64_t n_local, int64_t ld, int64_t col0,
+                                  const float *target_scores, const int64_t *obj_idx,
+                                  const int64_t *pair_slot, const int64_t *pair_ptr, const int64_t *pair_obj,
+                                  int32_t *counts_out, double *bce_rows_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,21 +9,31 @@
 // sort(stable=True) produce; torch's default CPU sort is unstable, so the reference's own
 // tie order on CPU is unspecified).  Optionally it also returns the row's BCE sum
 // (nn.BCELoss with 0/1 targets, logs clamped at -100 like torch), train.py:113.
+//
+// Entity-sharded form ("better than gather"): a rank holds the columns
+// [col0, col0 + N) of the score matrix.  The count above is a sum over columns, so each rank counts
+// over its own block against the target's score (owned by one rank: rtk_target_scores_f32 +
+// all-reduce MAX) and the B partial counts are all-reduced -- B x 12 bytes cross the links instead
+// of B x N x 4.  The single-device entry point is the col0 = 0 case of the same kernel.
 #include "rtk_common.h"
 
 namespace {
 
+// PARTIAL: target scores come from pt_in, the "+1" is left to the caller, ids are global
+template <bool PARTIAL>
 __global__ __launch_bounds__(256) void filtered_rank_kernel(
-    const float *__restrict__ P, int B, int N, int64_t ld, const int64_t *__restrict__ obj_idx,
+    const float *__restrict__ P, int B, int N, int64_t ld, int64_t col0, const float *__restrict__ pt_in,
+    const int64_t *__restrict__ obj_idx,
     const int64_t *__restrict__ pair_slot, const int64_t *__restrict__ pair_ptr,
     const int64_t *__restrict__ pair_obj, int32_t *__restrict__ ranks, double *__restrict__ bce_rows) {
     __shared__ int s_gt[4], s_eq[4];
     __shared__ float s_bce[4];
     const int d = blockIdx.x, t = threadIdx.x;
     const float *row = P + (int64_t)d * ld;
-    int64_t tgt = obj_idx[d];
-    tgt = tgt < 0 ? 0 : (tgt >= N ? N - 1 : tgt);
-    const float pt = row[tgt];
+    int64_t tgt = obj_idx[d] - col0;            // local column of the queried object (outside [0, N): another rank's)
+    if (!PARTIAL) tgt = tgt < 0 ? 0 : (tgt >= N ? N - 1 : tgt);
+    const bool own = tgt >= 0 && tgt < N;
+    const float pt = PARTIAL ? pt_in[d] : row[tgt];
     int gt = 0, eq = 0;
     float bce = 0.f;
     const bool want_bce = bce_rows != nullptr;
@@ -37,7 +47,7 @@ __global__ __launch_bounds__(256) void filtered_rank_kernel(
     const int64_t s = pair_slot ? pair_slot[d] : -1;
     if (s >= 0) {
         for (int64_t i = pair_ptr[s] + t; i < pair_ptr[s + 1]; i += 256) {
-            const int64_t j = pair_obj[i];
+            const int64_t j = pair_obj[i] - col0;
             if (j < 0 || j >= N) continue;
             const float p = row[j];
             if (want_bce) bce += fmaxf(logf(p), -100.0f) - fmaxf(logf(1.0f - p), -100.0f);
@@ -46,7 +56,7 @@ __global__ __launch_bounds__(256) void filtered_rank_kernel(
             eq -= (p == pt) & (j < tgt);
             eq += (0.0f == pt) & (j < tgt);     // now a 0: ties only with a zero target score
         }
-    } else if (want_bce && t == 0) {            // no filter list: the queried object is the only positive
+    } else if (want_bce && t == 0 && own) {     // no filter list: the queried object is the only positive
         bce += fmaxf(logf(pt), -100.0f) - fmaxf(logf(1.0f - pt), -100.0f);
     }
 #pragma unroll
@@ -62,12 +72,44 @@ __global__ __launch_bounds__(256) void filtered_rank_kernel(
     }
     __syncthreads();
     if (t == 0) {
-        ranks[d] = 1 + s_gt[0] + s_gt[1] + s_gt[2] + s_gt[3] + s_eq[0] + s_eq[1] + s_eq[2] + s_eq[3];
+        ranks[d] = (PARTIAL ? 0 : 1) + s_gt[0] + s_gt[1] + s_gt[2] + s_gt[3] + s_eq[0] + s_eq[1] + s_eq[2] + s_eq[3];
         if (want_bce) bce_rows[d] = -((double)s_bce[0] + (double)s_bce[1] + (double)s_bce[2] + (double)s_bce[3]);
     }
 }
 
+__global__ __launch_bounds__(256) void target_scores_kernel(const float *__restrict__ P, int B, int N, int64_t ld,
+                                                            int64_t col0, const int64_t *__restrict__ obj_idx,
+                                                            float *__restrict__ pt_out) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= B) return;
+    const int64_t j = obj_idx[d] - col0;
+    pt_out[d] = (j >= 0 && j < N) ? P[(int64_t)d * ld + j] : -INFINITY;
+}
+
 }  // namespace
+
+extern "C" int rtk_target_scores_f32(const float *P, int64_t batch, int64_t n_local, int64_t ld, int64_t col0,
+                                     const int64_t *obj_idx, float *pt_out, void *stream) {
+    RTK_REQUIRE(P && obj_idx && pt_out, RTK_ERR_BAD_ARG, "rtk_target_scores_f32: null operand");
+    RTK_REQUIRE(batch > 0 && n_local > 0 && ld >= n_local && col0 >= 0, RTK_ERR_BAD_ARG, "rtk_target_scores_f32: bad sizes");
+    RTK_REQUIRE(batch < (1ll << 31) && n_local < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_target_scores_f32: dimension too large");
+    hipLaunchKernelGGL(target_scores_kernel, dim3((unsigned)rtk_cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, P,
+                       (int)batch, (int)n_local, ld, col0, obj_idx, pt_out);
+    return rtk_check_launch("rtk_target_scores_f32");
+}
+
+extern "C" int rtk_filtered_rank_partial_f32(const float *P, int64_t batch, int64_t n_local, int64_t ld, int64_t col0,
+                                             const float *target_scores, const int64_t *obj_idx,
+                                             const int64_t *pair_slot, const int64_t *pair_ptr, const int64_t *pair_obj,
+                                             int32_t *counts_out, double *bce_rows_out, void *stream) {
+    RTK_REQUIRE(P && obj_idx && counts_out && target_scores, RTK_ERR_BAD_ARG, "rtk_filtered_rank_partial_f32: null operand");
+    RTK_REQUIRE(batch > 0 && n_local > 0 && ld >= n_local && col0 >= 0, RTK_ERR_BAD_ARG, "rtk_filtered_rank_partial_f32: bad sizes");
+    RTK_REQUIRE(!pair_slot || (pair_ptr && pair_obj), RTK_ERR_BAD_ARG, "rtk_filtered_rank_partial_f32: pair_slot without the CSR arrays");
+    RTK_REQUIRE(batch < (1ll << 31) && n_local < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_filtered_rank_partial_f32: dimension too large");
+    hipLaunchKernelGGL(filtered_rank_kernel<true>, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, P, (int)batch,
+                       (int)n_local, ld, col0, target_scores, obj_idx, pair_slot, pair_ptr, pair_obj, counts_out, bce_rows_out);
+    return rtk_check_launch("rtk_filtered_rank_partial_f32");
+}
 
 extern "C" int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t ld,
                                      const int64_t *obj_idx, const int64_t *pair_slot, const int64_t *pair_ptr,
@@ -77,7 +119,8 @@ extern "C" int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_en
     RTK_REQUIRE(batch > 0 && n_ent > 0 && ld >= n_ent, RTK_ERR_BAD_ARG, "rtk_filtered_rank_f32: bad sizes");
     RTK_REQUIRE(!pair_slot || (pair_ptr && pair_obj), RTK_ERR_BAD_ARG, "rtk_filtered_rank_f32: pair_slot without the CSR arrays");
     RTK_REQUIRE(batch < (1ll << 31) && n_ent < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_filtered_rank_f32: dimension too large");
-    hipLaunchKernelGGL(filtered_rank_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, P, (int)batch,
-                       (int)n_ent, ld, obj_idx, pair_slot, pair_ptr, pair_obj, ranks_out, bce_rows_out);
+    hipLaunchKernelGGL(filtered_rank_kernel<false>, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, P, (int)batch,
+                       (int)n_ent, ld, (int64_t)0, (const float *)nullptr, obj_idx, pair_slot, pair_ptr, pair_obj, ranks_out,
+                       bce_rows_out);
     return rtk_check_launch("rtk_filtered_rank_f32");
 }

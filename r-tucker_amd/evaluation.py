@@ -60,6 +60,50 @@ def filtered_ranks(P: torch.Tensor, obj_idx: torch.Tensor, flt: DeviceFilter = N
     return (ranks, bce) if want_bce else ranks
 
 
+def target_scores_block(P: torch.Tensor, obj_idx: torch.Tensor, col0: int) -> torch.Tensor:
+    """Scores of the queried objects that fall into this column block, -inf for the others
+    (step 1 of the sharded ranking; all-reduce MAX over the ranks completes it)."""
+    lib = _lib.load()
+    B, n_loc = P.shape
+    dev = P.device
+    obj = obj_idx.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+    pt = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        sp = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.rtk_target_scores_f32(P.data_ptr(), B, n_loc, P.stride(0), int(col0), obj.data_ptr(),
+                                             pt.data_ptr(), sp), "rtk_target_scores_f32")
+    return pt
+
+
+def rank_counts_block(P: torch.Tensor, obj_idx: torch.Tensor, col0: int, target_scores: torch.Tensor,
+                      flt: DeviceFilter = None, item_ids: torch.Tensor = None, want_bce: bool = False):
+    """This column block's share of the rank count (int32, B) and, optionally, of the BCE row sums
+    (step 2 of the sharded ranking; all-reduce SUM, then rank = 1 + count)."""
+    lib = _lib.load()
+    if not P.is_cuda or P.dtype != torch.float32 or P.dim() != 2 or P.stride(1) != 1:
+        raise RuntimeError("P must be a float32 (B, n_local) GPU tensor with unit column stride")
+    B, n_loc = P.shape
+    dev = P.device
+    obj = obj_idx.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    bce = torch.empty(B, dtype=torch.float64, device=dev) if want_bce else None
+    slot = ptr = objs = None
+    if flt is not None:
+        slot = flt.slot_of_item[item_ids.to(dev)].contiguous()
+        ptr, objs = flt.pair_ptr, flt.pair_obj
+    pt = target_scores.to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        sp = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.rtk_filtered_rank_partial_f32(P.data_ptr(), B, n_loc, P.stride(0), int(col0), pt.data_ptr(),
+                                                     obj.data_ptr(),
+                                                     slot.data_ptr() if slot is not None else None,
+                                                     ptr.data_ptr() if ptr is not None else None,
+                                                     objs.data_ptr() if objs is not None else None,
+                                                     counts.data_ptr(), bce.data_ptr() if want_bce else None, sp),
+                   "rtk_filtered_rank_partial_f32")
+    return (counts, bce) if want_bce else counts
+
+
 def metrics_from_ranks(ranks: torch.Tensor):
     """Batch SUMS like ``src/utils/metrics.py`` (mrr = sum 1/rank, hits@k = #(rank <= k))."""
     r = ranks.to(torch.float64)

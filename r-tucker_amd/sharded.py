@@ -99,3 +99,42 @@ class ShardedEntityScorer:
 
     def score(self, core, R, S, O_loc, subject_idx, relation_idx, **kw) -> torch.Tensor:
         return self.scores_rowmajor(self.score_gathered(core, R, S, O_loc, subject_idx, relation_idx, **kw))
+
+    # ---- ranking without the gather ("better than gather") -------------------
+    def filtered_ranks(self, core, R, S, O_loc, subject_idx, relation_idx, object_idx, flt=None, item_ids=None,
+                       want_bce=False, target_scores_fn=None, rank_counts_fn=None, **kw):
+        """Filtered rank of ``object_idx`` (global entity ids) for every query, with the entity
+        matrix row-sharded and NO exchange of scores: each rank scores its block, the target
+        scores are completed by one all-reduce(MAX) of B floats, the per-block counts by one
+        all-reduce(SUM) of B int32 (+ B doubles for the BCE sums).  Same numbers as
+        ``evaluation.filtered_ranks`` on the gathered matrix (the count is a sum over columns).
+
+        ``target_scores_fn`` / ``rank_counts_fn`` default to the HIP kernels
+        (``evaluation.target_scores_block`` / ``rank_counts_block``); tests inject CPU functions."""
+        if target_scores_fn is None or rank_counts_fn is None:
+            from .evaluation import rank_counts_block, target_scores_block
+            target_scores_fn = target_scores_fn or target_scores_block
+            rank_counts_fn = rank_counts_fn or rank_counts_block
+        B = int(subject_idx.numel())
+        n_loc, lo = self.shards.n_loc, self.rank * self.shards.n_loc
+        n_valid = max(0, min(n_loc, self.shards.n_ent - lo))      # the last shard's padding rows are not entities
+        g = self._buffer(B, core.device, torch.float32)
+        mine = g[self.rank][:, :n_loc]
+        self.local_score(core, R, S, O_loc, subject_idx, relation_idx, out=mine, **kw)
+        block = mine[:, :n_valid] if n_valid > 0 else None
+        pt = (target_scores_fn(block, object_idx, lo) if block is not None
+              else torch.full((B,), float("-inf"), dtype=torch.float32, device=core.device))
+        if self.world > 1:
+            dist.all_reduce(pt, op=dist.ReduceOp.MAX, group=self.group)
+        if block is not None:
+            res = rank_counts_fn(block, object_idx, lo, pt, flt, item_ids, want_bce)
+            counts, bce = res if want_bce else (res, None)
+        else:
+            counts = torch.zeros(B, dtype=torch.int32, device=core.device)
+            bce = torch.zeros(B, dtype=torch.float64, device=core.device) if want_bce else None
+        if self.world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+            if want_bce:
+                dist.all_reduce(bce, op=dist.ReduceOp.SUM, group=self.group)
+        ranks = counts + 1
+        return (ranks, bce) if want_bce else ranks

@@ -50,6 +50,49 @@ def test_ranks_tie_heavy_random_rows(rt):
         np.testing.assert_array_equal(r0.cpu().numpy(), orc.ranks_stable_ref(torch.from_numpy(P), torch.from_numpy(t1)).numpy())
 
 
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_sharded_rank_counts_sum_to_the_ranks(rt, shards):
+    """Column blocks of the score matrix ranked separately (rtk_target_scores_f32 + max,
+    rtk_filtered_rank_partial_f32 + sum: what ShardedEntityScorer.filtered_ranks all-reduces)
+    give exactly the ranks and BCE sums of the single-device kernel, ties and filters included."""
+    from r_tucker_amd.evaluation import rank_counts_block, target_scores_block
+    rng = np.random.default_rng(shards)
+    B, N = 53, 3001
+    P = rng.choice(np.asarray([0.0, 0.1, 0.5, 0.9, 1.0], dtype=np.float32), size=(B, N))
+    P[:, ::7] = rng.random((B, len(range(0, N, 7)))).astype(np.float32)
+    t = (rng.random((B, N)) < 0.02).astype(np.float32)
+    o = rng.integers(0, N, B)
+    t[np.arange(B), o] = 1
+    ptr = np.concatenate([[0], np.cumsum(t.sum(1).astype(np.int64))])
+    objs = np.concatenate([np.nonzero(t[d])[0] for d in range(B)]).astype(np.int64)
+
+    class F:
+        pair_ptr = torch.from_numpy(ptr).cuda()
+        pair_obj = torch.from_numpy(objs).cuda()
+        slot_of_item = torch.arange(B).cuda()
+    Pd, od, ids = torch.from_numpy(P).cuda(), torch.from_numpy(o).cuda(), torch.arange(B)
+    for flt in (F, None):
+        ref_ranks, ref_bce = rt.filtered_ranks(Pd, od, flt, ids if flt else None, want_bce=True)
+        n_loc = -(-N // shards)
+        blocks = [(lo, Pd[:, lo:min(lo + n_loc, N)]) for lo in range(0, N, n_loc)]      # strided views: ld = N
+        pt = torch.stack([target_scores_block(blk, od, lo) for lo, blk in blocks]).max(dim=0).values
+        assert torch.equal(pt, Pd[torch.arange(B).cuda(), od])
+        parts = [rank_counts_block(blk, od, lo, pt, flt, ids if flt else None, want_bce=True) for lo, blk in blocks]
+        counts = torch.stack([c for c, _ in parts]).sum(dim=0)
+        bce = torch.stack([b for _, b in parts]).sum(dim=0)
+        assert torch.equal(counts + 1, ref_ranks)
+        assert torch.allclose(bce, ref_bce, rtol=1e-6, atol=1e-6)
+    # world 1: the scorer's own entry point is the same computation
+    from r_tucker_amd.sharded import ShardedEntityScorer
+    n_ent, n_rel, rank3 = 700, 6, (4, 24, 24)
+    core, R, S, O = [torch.from_numpy(x).cuda() for x in gen.make_params(n_ent, n_rel, rank3, 3)]
+    h, r = [torch.from_numpy(x).cuda() for x in gen.make_queries(n_ent, n_rel, 40, 3)]
+    obj = torch.from_numpy(np.random.default_rng(3).integers(0, n_ent, 40)).cuda()
+    sc = ShardedEntityScorer(n_ent)
+    ranks = sc.filtered_ranks(core, R, S, sc.local_block(O), h, r, obj)
+    assert torch.equal(ranks, rt.filtered_ranks(rt.score_1vN(core, R, S, O, h, r), obj))
+
+
 @pytest.mark.parametrize("variant", ["planted", "planted_sat", "spread"])
 def test_device_evaluate_wn18rr(rt, golden, golden_meta, variant):
     from r_tucker_amd.data import Data, KG_dataset

@@ -49,6 +49,83 @@ def _worker(rank, world, port, n_ent, n_rel, B, rank3, q):
         dist.destroy_process_group()
 
 
+class _Flt:
+    """The three arrays of evaluation.DeviceFilter, on the CPU."""
+    def __init__(self, slot_of_item, pair_ptr, pair_obj):
+        self.slot_of_item, self.pair_ptr, self.pair_obj = slot_of_item, pair_ptr, pair_obj
+
+
+def _cpu_target_scores(block, obj, col0):
+    j = obj - col0
+    own = (j >= 0) & (j < block.shape[1])
+    pt = torch.full((block.shape[0],), float("-inf"))
+    pt[own] = block[own.nonzero().view(-1), j[own]]
+    return pt
+
+
+def _cpu_rank_counts(block, obj, col0, pt, flt, item_ids, want_bce):
+    """Plain restatement of what rtk_filtered_rank_partial_f32 counts, for one column block."""
+    B, n = block.shape
+    counts = torch.zeros(B, dtype=torch.int32)
+    for d in range(B):
+        p = block[d].clone()
+        t = int(obj[d]) - col0
+        if flt is not None:
+            s = int(flt.slot_of_item[item_ids[d]])
+            for g in flt.pair_obj[flt.pair_ptr[s]:flt.pair_ptr[s + 1]].tolist():
+                if 0 <= g - col0 < n and g - col0 != t:
+                    p[g - col0] = 0.0
+        before = torch.arange(n) < t
+        counts[d] = int((p > pt[d]).sum() + ((p == pt[d]) & before).sum())
+    return (counts, torch.zeros(B, dtype=torch.float64)) if want_bce else counts
+
+
+def _rank_worker(rank, world, port, n_ent, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from r_tucker_amd.sharded import ShardedEntityScorer
+        n_rel, B, rank3 = 5, 24, (3, 8, 8)
+        core, R, S, O = [torch.from_numpy(x) for x in gen.make_params(n_ent, n_rel, rank3, 9)]
+        O = (O * 8).round() / 8                       # coarse values -> exact ties between scores
+        S = (S * 4).round() / 4
+        h, r = [torch.from_numpy(x) for x in gen.make_queries(n_ent, n_rel, B, 9)]
+        rng = np.random.default_rng(9)
+        obj = torch.from_numpy(rng.integers(0, n_ent, B))
+        # one filter list per query: the queried object plus up to 5 other known-true objects
+        lists = [sorted(set([int(obj[d])] + rng.integers(0, n_ent, rng.integers(0, 6)).tolist())) for d in range(B)]
+        ptr = torch.tensor(np.concatenate([[0], np.cumsum([len(x) for x in lists])]), dtype=torch.int64)
+        flt = _Flt(torch.arange(B), ptr, torch.tensor([x for l in lists for x in l], dtype=torch.int64))
+        sc = ShardedEntityScorer(n_ent, local_score=_oracle_local)
+        ranks = sc.filtered_ranks(core, R, S, sc.local_block(O), h, r, obj, flt, torch.arange(B),
+                                  target_scores_fn=_cpu_target_scores, rank_counts_fn=_cpu_rank_counts)
+        P = orc.score_ref(core, R, S, O, h, r)
+        targets = torch.zeros_like(P)
+        for d, l in enumerate(lists):
+            targets[d, l] = 1.0
+        ref = orc.filter_and_rank_stable(P, targets, obj)
+        q.put((rank, bool(torch.equal(ranks.long(), ref.long())), int((ranks.long() - ref.long()).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ent", [64, 101])
+def test_sharded_filtered_ranks_world2_gloo(n_ent):
+    """Ranking without the gather: per-block counts + two small all-reduces give the ranks the
+    oracle computes on the full score matrix (stable tie order, filtered objects zeroed)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_worker, args=(rk, 2, port, n_ent, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert [r[1] for r in res] == [True, True], res
+
+
 @pytest.mark.parametrize("n_ent", [64, 101])      # even and ragged (last shard padded)
 def test_sharded_scorer_world2_gloo(n_ent):
     ctx = mp.get_context("spawn")
