@@ -199,6 +199,25 @@ int rtk_filtered_rank_partial_f32(const float *P, int64_t batch, int64_t n_local
                                   const int64_t *pair_slot, const int64_t *pair_ptr, const int64_t *pair_obj,
                                   int32_t *counts_out, double *bce_rows_out, void *stream);
 
+/*
+ * Training loss without dense targets (train.py:76-82 with criterion = nn.BCELoss, train.py:136;
+ * targets as src/data/Dataset.py:43-53 builds them: y = (1 - eps) * multi_hot + eps / N).
+ * The multi-hot part is the CSR of known objects per (subject, relation) pair (pair_slot per row;
+ * every object of a pair listed once).
+ *   rtk_bce_rows_f32  rows_out[d] = sum_j BCE(P[d,j], y[d,j])  (double; logs clamped at -100 like
+ *                     torch); the reference's mean loss is sum(rows_out) / (batch * n_ent)
+ *   rtk_bce_grad_f32  in place  P[d,j] <- (P[d,j] - y[d,j]) * grad_loss[0] * scale : with
+ *                     scale = 1 / (batch * n_ent) this is d loss / d logits (P = sigmoid(logits)),
+ *                     the left operand of the dO / dv GEMMs.  grad_loss is a DEVICE scalar.
+ */
+int rtk_bce_rows_f32(const float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
+                     const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
+                     double *rows_out, void *stream);
+
+int rtk_bce_grad_f32(float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
+                     const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
+                     const float *grad_loss, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

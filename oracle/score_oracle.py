@@ -206,3 +206,21 @@ def filter_and_rank_stable(predictions, targets, object_idx):
 def bce_mean_ref(predictions, targets):
     """``nn.BCELoss(reduction="mean")(predictions, targets)`` -- train.py:113,136."""
     return torch.nn.functional.binary_cross_entropy(predictions, targets, reduction="mean")
+
+
+def bce_loss_grads_ref(core, R, S, O, subject_idx, relation_idx, targets, shared=False):
+    """Training loss term of train.py:79 (``criterion(score_fn(T), targets)`` with
+    ``nn.BCELoss()``, train.py:136) and its gradients w.r.t. the Tucker operands, by torch autograd
+    on CPU through the reference op sequence.  ``targets``: the dense label-smoothed matrix the
+    reference's Dataset builds (Dataset.py:43-53).  Returns (loss, g_core, g_R, g_S[, g_O])."""
+    core = core.detach().clone().requires_grad_(True)
+    R = R.detach().clone().requires_grad_(True)
+    S = S.detach().clone().requires_grad_(True)
+    if shared:
+        loss = bce_mean_ref(score_ref(core, R, S, S, subject_idx, relation_idx), targets)
+        loss.backward()
+        return loss.detach(), core.grad, R.grad, S.grad
+    O = O.detach().clone().requires_grad_(True)
+    loss = bce_mean_ref(score_ref(core, R, S, O, subject_idx, relation_idx), targets)
+    loss.backward()
+    return loss.detach(), core.grad, R.grad, S.grad, O.grad

@@ -39,6 +39,8 @@ SIGNATURES = {
     "rtk_gemm_f32_splitk": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _i, _p]),
     "rtk_sigmoid_grad_f32": (_i, [_p, _p, _p, _i64, _p]),
     "rtk_filtered_rank_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "rtk_bce_rows_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, _p]),
+    "rtk_bce_grad_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, C.c_float, _p]),
     "rtk_target_scores_f32": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p]),
     "rtk_filtered_rank_partial_f32": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
 }

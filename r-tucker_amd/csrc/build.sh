@@ -6,7 +6,7 @@ OUT=../lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-function"
 pids=()
-for f in rtk_abi rtk_gemm_f32 rtk_query rtk_score_split rtk_score_ws rtk_score_ws2 rtk_score_bf16 rtk_rank; do
+for f in rtk_abi rtk_gemm_f32 rtk_query rtk_score_split rtk_score_ws rtk_score_ws2 rtk_score_bf16 rtk_rank rtk_bce; do
   ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
   pids+=($!)
 done

@@ -1,0 +1,126 @@
+// Training loss without dense targets.  The reference builds, per item, a dense
+// N-vector of label-smoothed targets on the host (src/data/Dataset.py:43-53:
+// y = (1 - eps) * multi_hot + eps / N), ships B x N floats per batch to the device and lets
+// nn.BCELoss read scores and targets again (train.py:76-82, :136).  Here the targets exist only as
+// the CSR of known objects per (subject, relation) pair, uploaded once:
+//   rtk_bce_rows_f32 : per-row sum of BCE terms           (forward:  loss = sum / (B * N))
+//   rtk_bce_grad_f32 : P <- (P - y) * g * scale, in place (backward: d loss / d logits, because
+//                      d BCE / d z = p - y for p = sigmoid(z)), ready for the dO / dv GEMMs.
+// Both are one pass over the B x N scores plus a pass over the few positives.
+// The CSR must hold every object of a pair ONCE (evaluation.DeviceFilter de-duplicates).
+#include "rtk_common.h"
+
+namespace {
+
+__device__ __forceinline__ float clog(float x) { return fmaxf(logf(x), -100.0f); }   // torch clamps BCE's logs at -100
+
+// one workgroup per row
+__global__ __launch_bounds__(256) void bce_rows_kernel(const float *__restrict__ P, int N, int64_t ld, float t0, float dt,
+                                                       const int64_t *__restrict__ pair_slot,
+                                                       const int64_t *__restrict__ pair_ptr,
+                                                       const int64_t *__restrict__ pair_obj,
+                                                       double *__restrict__ rows) {
+    __shared__ double s_sum[4];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const float *row = P + (int64_t)d * ld;
+    // every entity as a smoothed negative: y = t0 = eps / N
+    float acc = 0.f;
+    for (int j = t; j < N; j += 256) {
+        const float p = row[j];
+        acc += t0 * clog(p) + (1.0f - t0) * clog(1.0f - p);
+    }
+    // the pair's known objects: y = t0 + dt, dt = 1 - eps
+    const int64_t s = pair_slot[d];
+    for (int64_t i = pair_ptr[s] + t; i < pair_ptr[s + 1]; i += 256) {
+        const int64_t j = pair_obj[i];
+        if (j < 0 || j >= N) continue;
+        const float p = row[j];
+        acc += dt * (clog(p) - clog(1.0f - p));
+    }
+    double a = (double)acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((t & 63) == 0) s_sum[t >> 6] = a;
+    __syncthreads();
+    if (t == 0) rows[d] = -(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+
+// P <- (P - t0) * g * scale for every element (grid-stride over rows x column chunks)
+template <bool VEC>
+__global__ __launch_bounds__(256) void bce_grad_all_kernel(float *__restrict__ P, int B, int N, int64_t ld, float t0,
+                                                           const float *__restrict__ g, float scale) {
+    const float s = g[0] * scale;
+    const int d = blockIdx.y;
+    float *row = P + (int64_t)d * ld;
+    if (VEC) {
+        const int n4 = N >> 2;
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+            f32x4 x = reinterpret_cast<f32x4 *>(row)[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = (x[e] - t0) * s;
+            reinterpret_cast<f32x4 *>(row)[q] = x;
+        }
+        for (int j = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) row[j] = (row[j] - t0) * s;
+    } else {
+        for (int j = blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) row[j] = (row[j] - t0) * s;
+    }
+}
+
+// the positives: their target was t0 + dt
+__global__ __launch_bounds__(64) void bce_grad_pos_kernel(float *__restrict__ P, int N, int64_t ld, float dt,
+                                                          const float *__restrict__ g, float scale,
+                                                          const int64_t *__restrict__ pair_slot,
+                                                          const int64_t *__restrict__ pair_ptr,
+                                                          const int64_t *__restrict__ pair_obj) {
+    const int d = blockIdx.x;
+    const float s = g[0] * scale * dt;
+    float *row = P + (int64_t)d * ld;
+    const int64_t sl = pair_slot[d];
+    for (int64_t i = pair_ptr[sl] + threadIdx.x; i < pair_ptr[sl + 1]; i += 64) {
+        const int64_t j = pair_obj[i];
+        if (j >= 0 && j < N) row[j] -= s;
+    }
+}
+
+int check(const char *fn, const float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
+          const int64_t *pair_ptr, const int64_t *pair_obj, float eps) {
+    RTK_REQUIRE(P && pair_slot && pair_ptr && pair_obj, RTK_ERR_BAD_ARG, "%s: null operand", fn);
+    RTK_REQUIRE(batch > 0 && n_ent > 0 && ld >= n_ent, RTK_ERR_BAD_ARG, "%s: bad sizes", fn);
+    RTK_REQUIRE(eps >= 0.f && eps < 1.f, RTK_ERR_BAD_ARG, "%s: label smoothing %g outside [0, 1)", fn, (double)eps);
+    RTK_REQUIRE(batch < 65536 * 16384ll && n_ent < (1ll << 31), RTK_ERR_UNSUPPORTED, "%s: dimension too large", fn);
+    return RTK_OK;
+}
+
+}  // namespace
+
+extern "C" int rtk_bce_rows_f32(const float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
+                                const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
+                                double *rows_out, void *stream) {
+    int rc = check("rtk_bce_rows_f32", P, batch, n_ent, ld, pair_slot, pair_ptr, pair_obj, label_smoothing);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(rows_out, RTK_ERR_BAD_ARG, "rtk_bce_rows_f32: null output");
+    RTK_REQUIRE(batch < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_bce_rows_f32: batch too large");
+    const float t0 = label_smoothing / (float)n_ent, dt = 1.0f - label_smoothing;
+    hipLaunchKernelGGL(bce_rows_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, P, (int)n_ent, ld, t0, dt,
+                       pair_slot, pair_ptr, pair_obj, rows_out);
+    return rtk_check_launch("rtk_bce_rows_f32");
+}
+
+extern "C" int rtk_bce_grad_f32(float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
+                                const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
+                                const float *grad_loss, float scale, void *stream) {
+    int rc = check("rtk_bce_grad_f32", P, batch, n_ent, ld, pair_slot, pair_ptr, pair_obj, label_smoothing);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(grad_loss, RTK_ERR_BAD_ARG, "rtk_bce_grad_f32: null grad_loss");
+    RTK_REQUIRE(batch <= 65535, RTK_ERR_UNSUPPORTED, "rtk_bce_grad_f32: batch > 65535");
+    const float t0 = label_smoothing / (float)n_ent, dt = 1.0f - label_smoothing;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+    const unsigned gx = (unsigned)(rtk_cdiv(n_ent, 1024 * 4) < 1 ? 1 : rtk_cdiv(n_ent, 1024 * 4));
+    dim3 grid(gx < 64 ? gx : 64, (unsigned)batch);
+    if (vec) hipLaunchKernelGGL((bce_grad_all_kernel<true>), grid, dim3(256), 0, st, P, (int)batch, (int)n_ent, ld, t0, grad_loss, scale);
+    else hipLaunchKernelGGL((bce_grad_all_kernel<false>), grid, dim3(256), 0, st, P, (int)batch, (int)n_ent, ld, t0, grad_loss, scale);
+    hipLaunchKernelGGL(bce_grad_pos_kernel, dim3((unsigned)batch), dim3(64), 0, st, P, (int)n_ent, ld, dt, grad_loss, scale,
+                       pair_slot, pair_ptr, pair_obj);
+    return rtk_check_launch("rtk_bce_grad_f32");
+}

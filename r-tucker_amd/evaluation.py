@@ -24,8 +24,16 @@ class DeviceFilter:
 
     def __init__(self, dataset, device):
         self.device = torch.device(device)
-        self.pair_ptr = torch.as_tensor(np.asarray(dataset._ptr, dtype=np.int64), device=self.device)
-        self.pair_obj = torch.as_tensor(np.asarray(dataset._obj, dtype=np.int64), device=self.device)
+        # every object of a pair once (the dense targets of Dataset.py:43-50 are idempotent under
+        # repeated triples; the kernels that walk the CSR are not)
+        ptr, obj = np.asarray(dataset._ptr, dtype=np.int64), np.asarray(dataset._obj, dtype=np.int64)
+        seg = np.repeat(np.arange(len(ptr) - 1, dtype=np.int64), np.diff(ptr))
+        key = np.unique(seg * (int(obj.max()) + 1 if len(obj) else 1) + obj)
+        m = int(obj.max()) + 1 if len(obj) else 1
+        ptr = np.concatenate([[0], np.cumsum(np.bincount(key // m, minlength=len(ptr) - 1))]).astype(np.int64)
+        obj = (key % m).astype(np.int64)
+        self.pair_ptr = torch.as_tensor(ptr, device=self.device)
+        self.pair_obj = torch.as_tensor(obj, device=self.device)
         f = dataset.features
         slots = np.fromiter((dataset._pair_slot[(int(s), int(r))] for s, r in f[:, :2]), dtype=np.int64, count=len(f))
         self.slot_of_item = torch.as_tensor(slots, device=self.device)

@@ -187,30 +187,95 @@ class _Score1vN(torch.autograd.Function):
                            "rtk_sigmoid_grad_f32")
             else:
                 dZ = grad_out
-            gO = None
-            if ctx.needs_input_grad[3]:
-                # gO[j, k] = sum_d dZ[d, j] * v[d, k]   -- fp32 MFMA GEMM, both operands M-major
-                gO = torch.empty((N, c), dtype=torch.float32, device=dev)
-                _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, N, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
-                           "rtk_gemm_f32 (dO)")
-            # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K with float atomics
-            Of = O.contiguous()
-            dv = torch.empty((B, c), dtype=torch.float32, device=dev)
-            splits = max(1, min(256, N // 512))
-            _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, N, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
-                                               splits, sp), "rtk_gemm_f32_splitk (dv)")
-        Rb, Sb = R[r], S[h]
-        W = torch.einsum("abc,dc->dab", core, dv)                            # (B, a, b)
-        gcore = torch.einsum("da,db,dc->abc", Rb, Sb, dv) if ctx.needs_input_grad[0] else None
-        gR = gS = None
-        if ctx.needs_input_grad[1]:
-            gR = torch.zeros_like(R).index_add_(0, r, torch.einsum("dab,db->da", W, Sb))
-        if ctx.needs_input_grad[2]:
-            gS = torch.zeros_like(S).index_add_(0, h, torch.einsum("dab,da->db", W, Rb))
+        return _grads_from_dZ(core, R, S, O, h, r, v, dZ, ctx.needs_input_grad, pdt) + (None,) * 5
+
+
+def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt):
+    """(g_core, g_R, g_S, g_O) from dZ = d loss / d logits (B, N) fp32 and the saved fp32 query
+    vectors: the two B x N-sized products are HIP GEMMs, the small trilinear remainder torch ops."""
+    lib = _lib.load()
+    dev = dZ.device
+    B, N = dZ.shape
+    c = O.shape[1]
+    with torch.cuda.device(dev):
+        sp = _stream_ptr(dev)
+        gO = None
+        if needs[3]:
+            # gO[j, k] = sum_d dZ[d, j] * v[d, k]   -- fp32 MFMA GEMM, both operands M-major
+            gO = torch.empty((N, c), dtype=torch.float32, device=dev)
+            _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, N, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
+                       "rtk_gemm_f32 (dO)")
+        # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K with float atomics
+        Of = O.contiguous()
+        dv = torch.empty((B, c), dtype=torch.float32, device=dev)
+        splits = max(1, min(256, N // 512))
+        _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, N, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
+                                           splits, sp), "rtk_gemm_f32_splitk (dv)")
+    Rb, Sb = R[r], S[h]
+    W = torch.einsum("abc,dc->dab", core, dv)                            # (B, a, b)
+    gcore = torch.einsum("da,db,dc->abc", Rb, Sb, dv) if needs[0] else None
+    gR = gS = None
+    if needs[1]:
+        gR = torch.zeros_like(R).index_add_(0, r, torch.einsum("dab,db->da", W, Sb))
+    if needs[2]:
+        gS = torch.zeros_like(S).index_add_(0, h, torch.einsum("dab,da->db", W, Rb))
+    if pdt != torch.float32:
+        gcore, gR, gS, gO = [g.to(pdt) if g is not None else None for g in (gcore, gR, gS, gO)]
+    # symmetric model: S and O are the same tensor passed twice; autograd sums gS + gO
+    return gcore, gR, gS, gO
+
+
+class _BceLoss1vN(torch.autograd.Function):
+    """mean BCE(sigmoid(logits), smoothed multi-hot targets) with the targets given as a CSR."""
+
+    @staticmethod
+    def forward(ctx, core, R, S, O, subject_idx, relation_idx, pair_slot, pair_ptr, pair_obj, label_smoothing):
+        P, v = _forward(core, R, S, O, subject_idx, relation_idx, True, False, want_v=True)
+        lib = _lib.load()
+        dev = P.device
+        B, N = P.shape
+        rows = torch.empty(B, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rtk_bce_rows_f32(P.data_ptr(), B, N, P.stride(0), pair_slot.data_ptr(), pair_ptr.data_ptr(),
+                                            pair_obj.data_ptr(), float(label_smoothing), rows.data_ptr(), _stream_ptr(dev)),
+                       "rtk_bce_rows_f32")
+        ctx.save_for_backward(core, R, S, O, _idx("s", subject_idx, dev), _idx("r", relation_idx, dev), v, P,
+                              pair_slot, pair_ptr, pair_obj)
+        ctx.eps = float(label_smoothing)
+        return (rows.sum() / (B * N)).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        core, R, S, O, h, r, v, P, pair_slot, pair_ptr, pair_obj = ctx.saved_tensors
+        if getattr(ctx, "spent", False):
+            raise RuntimeError("bce_loss_1vN: backward called twice (the saved scores are overwritten by the first pass)")
+        ctx.spent = True
+        pdt = core.dtype
         if pdt != torch.float32:
-            gcore, gR, gS, gO = [g.to(pdt) if g is not None else None for g in (gcore, gR, gS, gO)]
-        # symmetric model: S and O are the same tensor passed twice; autograd sums gS + gO
-        return gcore, gR, gS, gO, None, None, None, None, None
+            core, R, S, O = core.float(), R.float(), S.float(), O.float()
+        lib = _lib.load()
+        dev = P.device
+        B, N = P.shape
+        g = grad_loss.to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(dev):
+            # in place: P <- (P - y) * g / (B * N) = d loss / d logits  (the saved scores are spent)
+            _lib.check(lib.rtk_bce_grad_f32(P.data_ptr(), B, N, P.stride(0), pair_slot.data_ptr(), pair_ptr.data_ptr(),
+                                            pair_obj.data_ptr(), ctx.eps, g.data_ptr(), 1.0 / (B * N), _stream_ptr(dev)),
+                       "rtk_bce_grad_f32")
+        return _grads_from_dZ(core, R, S, O, h, r, v, P, ctx.needs_input_grad, pdt) + (None,) * 6
+
+
+def bce_loss_1vN(core, R, S, O, subject_idx, relation_idx, flt, item_ids, label_smoothing=0.0):
+    """The reference's training loss term ``nn.BCELoss()(score_fn(T), targets)`` (train.py:79,136) for a
+    batch of (subject, relation) items WITHOUT the dense target matrix: ``flt`` is the
+    ``evaluation.DeviceFilter`` of the train-mode ``KG_dataset`` (CSR of known objects per pair, on
+    the device), ``item_ids`` the dataset indices of the batch; the targets
+    ``(1 - eps) * multi_hot + eps / N`` (Dataset.py:51-52) are applied inside the kernels.
+    Differentiable w.r.t. core and factors like ``score_1vN``."""
+    dev = core.device
+    slot = flt.slot_of_item[item_ids.to(dev)].contiguous()
+    return _BceLoss1vN.apply(core, R, S, O, subject_idx, relation_idx, slot, flt.pair_ptr, flt.pair_obj,
+                             float(label_smoothing))
 
 
 def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=False, sigmoid_mode=None):
