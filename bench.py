@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--workload", default="wn18rr_asym_r10x200_b512_f32", choices=sorted(WORKLOADS))
     ap.add_argument("--exact", action="store_true", help="exact-fp32 MFMA score kernel instead of split-fp16")
     ap.add_argument("--sigmoid", default=None, choices=["fast", "exact"], help="logistic of the fused epilogue (default: package default)")
+    ap.add_argument("--out-dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 workloads: dtype of the score matrix (bf16 = what the reference's bf16 model returns)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,9 +137,15 @@ def main():
     # rank p's (B, n_loc) block is slot p of the gather buffer: the kernel writes its block in place
     # row pitch of the score block: rows start on 128-byte boundaries (r_tucker_amd.ops.ROW_ALIGN,
     # the layout score_1vN allocates; R_TUCKER_AMD_ROW_ALIGN=1 gives the dense (B, n_loc) layout)
-    ra = _ops.ROW_ALIGN
+    obf = args.out_dtype == "bf16"
+    if obf and (not bf16 or args.exact or sig_mode != "fast"):
+        raise SystemExit("--out-dtype bf16 needs a bf16 workload and the fast logistic")
+    osz = 2 if obf else 4
+    ra = _ops.ROW_ALIGN * (4 // osz) if _ops.ROW_ALIGN > 1 else 1
     pitch = -(-n_loc // ra) * ra
-    gathered = torch.empty((world, B, pitch), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, B, pitch), dtype=torch.bfloat16 if obf else torch.float32, device=dev)
+    if obf:
+        sflags |= _lib.RTK_SCORE_OUT_BF16
     out = gathered[rank]
 
     stream = torch.cuda.current_stream(dev)
@@ -201,7 +209,7 @@ def main():
     gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if world > 1 else None
     # algorithmic bytes of ONE score-kernel launch: read the O shard once, write the scores once,
     # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
-    alg_bytes = n_loc * c * esz + B * n_loc * 4 + B * c * esz
+    alg_bytes = n_loc * c * esz + B * n_loc * osz + B * c * esz
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if they match
     try:
@@ -216,7 +224,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": args.workload, "entities": n_ent, "relations": n_rel, "rank": list(trank),
-                   "batch": B, "scores_per_query": n_ent, "score_row_pitch": pitch,
+                   "batch": B, "scores_per_query": n_ent, "score_row_pitch": pitch, "score_dtype": args.out_dtype,
                    "score_kernel": "exact_f32_mfma" if args.exact else ("bf16_mfma" if bf16 else "split_fp16_mfma"),
                    "sigmoid": "exact" if args.exact else sig_mode,
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
@@ -229,7 +237,7 @@ def main():
     if world > 1:
         # the exchange step: every rank receives (P-1) blocks of B*n_loc fp32 over xGMI
         # (7 links x ~153 GB/s per GPU, MI355X guide); reported next to the shard-local rate
-        recv = (world - 1) * B * pitch * 4
+        recv = (world - 1) * B * pitch * osz
         result["exchange"] = {"collective": "all_gather_into_tensor (RCCL, in place)", "ms": gather_ms,
                               "bytes_received_per_gpu": recv, "achieved_GBps": recv / (gather_ms * 1e-3) / 1e9,
                               "xgmi_peak_GBps": 7 * 153.0, "frac": recv / (gather_ms * 1e-3) / 1e9 / (7 * 153.0),

@@ -56,6 +56,10 @@ typedef enum rtk_dtype {
 #define RTK_SCORE_SIGMOID_FAST 4u /* with RTK_SCORE_SIGMOID: 1 / (1 + 2^(-z log2 e)) on  */
                                   /* v_exp_f32 + v_rcp_f32 (1 ulp each) instead of expf */
                                   /* + IEEE divide                                      */
+#define RTK_SCORE_OUT_BF16 8u     /* bf16 operand entry points, with SIGMOID | SIGMOID_FAST:   */
+                                  /* `out` holds bf16 scores (what the reference's bf16 model */
+                                  /* returns), ld_out counts bf16 elements; pass the pointer  */
+                                  /* through the float* parameter                              */
 
 int rtk_version(void);
 const char *rtk_last_error_string(void);

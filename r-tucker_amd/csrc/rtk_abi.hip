@@ -160,5 +160,5 @@ extern "C" int rtk_score_1vN_bf16(const void *core, int a, int b, int c, const v
                                      ws.q_packed, ws, (hipStream_t)stream);
     if (rc != RTK_OK) return rc;
     return rtk_score_packed_bf16(ws.q_packed, batch, c, O, n_local, out, ld_out,
-                                 flags & (RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST), stream);
+                                 flags & (RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST | RTK_SCORE_OUT_BF16), stream);
 }

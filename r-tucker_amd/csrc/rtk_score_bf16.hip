@@ -19,7 +19,7 @@ namespace {
 // so its L2 -> CU traffic per score is 2*K / (32*NW) bytes (K = 512, NW = 4: 8 B per 4-B score).
 // QB = query tiles per block of the sweep: every workgroup walks the query blocks in the same
 // order, so the chip works on one block (QB tiles, <= ~1.5 MB) at a time and it stays in the L2s.
-template <int KS, int SIGMOID, int MINW, int NW, bool NTS>
+template <int KS, int SIGMOID, int MINW, int NW, bool NTS, bool OBF>
 __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
     const unsigned char *__restrict__ q_packed, int B, const rtk_bf16 *__restrict__ O, int N, int c,
     float *__restrict__ out, int64_t ld_out, bool o_vec, int QB) {
@@ -79,18 +79,28 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
                 if (i + 1 < NLD || ch < CHUNKS) dst[ch] = stg[i];
             }
         };
-        const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
-        const unsigned ld4 = (unsigned)(ld_out * 4);
+        // OBF: bf16 scores (what the reference's bf16 model returns).  Adjacent lanes (columns j, j + 1)
+        // trade one value per row pair through DPP so that each holds two neighbouring columns of ONE
+        // row, rounds them with v_cvt_pk_bf16_f32 and stores 4 bytes: the even lane the pair's first
+        // row, the odd lane its second.
+        constexpr int ES = OBF ? 2 : 4;              // bytes per score
+        const int par = lane & 1, c0 = j & ~1;       // OBF: first column of this lane's pair
+        const unsigned voff = !OBF ? ((j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u)
+                                   : ((c0 + 1 < N) ? (unsigned)(((4 * h + par) * ld_out + c0) * 2) : 0x80000000u);
+        const unsigned voff_last = (OBF && c0 + 1 == N) ? (unsigned)(((4 * h + par) * ld_out + c0) * 2) : 0x80000000u;
+        const bool n_odd = OBF && (N & 1);           // then the last column is stored on its own (2 bytes)
+        const unsigned ld4 = (unsigned)(ld_out * ES);
         __amdgpu_buffer_rsrc_t ers;
-        unsigned ep_off = voff;
+        unsigned ep_off = voff, ep_off_last = voff_last;
         auto epilogue_begin = [&](int mt, bool live) {
             const int rows = live ? min(32, B - mt * 32) : 0;
-            ers = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)max(mt, 0) * 32 * ld_out, 0,
-                                                    (unsigned)(rows * ld_out * 4), 0x00020000);
+            ers = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char *>(out) + (int64_t)max(mt, 0) * 32 * ld_out * ES, 0,
+                                                    (unsigned)(rows * ld_out * ES), 0x00020000);
             ep_off = voff;
+            ep_off_last = voff_last;
             asm volatile("" : "+v"(ep_off));
         };
-        float ep_d = 1.f, ep_p = 1.f;
+        float ep_d = 1.f, ep_p = 1.f, ep_keep = 0.f;
         auto piece = [&](const f32x16 &z, int pc) {   // 32 pieces: 16 values x {exp half, reciprocal half + store}
             const int e = pc >> 1;
             if ((pc & 1) == 0) {
@@ -106,8 +116,25 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
                 if (SIGMOID == 2) pv = __builtin_amdgcn_rcpf(1.0f + ep_d);   // v_exp_f32 / v_rcp_f32 are 1-ulp
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
                 // NTS (128-B aligned rows): nontemporal -- the scores are written once and not re-read here
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, NTS ? 2 : 0);
-                ep_off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                if (!OBF) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, NTS ? 2 : 0);
+                    ep_off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                } else if (!(e & 1)) {
+                    ep_keep = pv;                    // first row of the pair: wait for the second
+                } else {
+                    const float send = par ? ep_keep : pv;
+                    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t pr = par ? f32x2_t{recv, pv} : f32x2_t{ep_keep, recv};   // (column c0, column c0 + 1)
+                    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_t));
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, ers, ep_off, 0, NTS ? 2 : 0);
+                    if (n_odd) {
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk & 0xffffu), ers, ep_off_last, 0, 0);
+                        ep_off_last += ((e & 3) == 3) ? 6u * ld4 : 2u * ld4;
+                    }
+                    ep_off += ((e & 3) == 3) ? 6u * ld4 : 2u * ld4;   // row pairs 0/1, 2/3, 8/9, 10/11, 16/17, ...
+                }
             }
         };
 
@@ -152,13 +179,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
     }
 }
 
-template <int KS, int SG, int MINW, int NW, bool NTS>
+template <int KS, int SG, int MINW, int NW, bool NTS, bool OBF>
 void launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
                 hipStream_t st) {
     constexpr size_t tile = RTK_PACK_HDR + KS * 1024, smem = 2 * tile;
     static bool attr_set = false;
     if (smem > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW, NW, NTS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
@@ -168,35 +195,41 @@ void launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, 
     else qb = (int)rtk_cdiv(n_mt, rtk_cdiv(n_mt, qb));   // equal blocks
     const int64_t units = rtk_cdiv(N, 32 * NW) * (int64_t)qb;
     const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
-    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW, NW, NTS>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
+    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
 }
 
 template <int KS, int SG, int MINW, int NW>
 void launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
-                hipStream_t st) {
+                bool obf, hipStream_t st) {
     static const bool nts_off = getenv("RTK_NO_NT_STORES") != nullptr;
-    const bool nts = !nts_off && (ld * 4) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
-    if constexpr (SG != 1) {   // (the exact-logistic variant keeps one form)
-        if (nts) return launch_nt<KS, SG, MINW, NW, true>(qp, B, O, N, c, out, ld, o_vec, st);
+    const bool nts = !nts_off && (ld * (obf ? 2 : 4)) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
+    if constexpr (SG == 2) {   // bf16 scores: probabilities only (the caller checks)
+        if (obf) {
+            if (nts) return launch_nt<KS, SG, MINW, NW, true, true>(qp, B, O, N, c, out, ld, o_vec, st);
+            return launch_nt<KS, SG, MINW, NW, false, true>(qp, B, O, N, c, out, ld, o_vec, st);
+        }
     }
-    launch_nt<KS, SG, MINW, NW, false>(qp, B, O, N, c, out, ld, o_vec, st);
+    if constexpr (SG != 1) {   // (the exact-logistic variant keeps one form)
+        if (nts) return launch_nt<KS, SG, MINW, NW, true, false>(qp, B, O, N, c, out, ld, o_vec, st);
+    }
+    launch_nt<KS, SG, MINW, NW, false, false>(qp, B, O, N, c, out, ld, o_vec, st);
 }
 
 template <int KS, int MINW, int NW>
 void launch_ks(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, int sg,
-               bool o_vec, hipStream_t st) {
-    if (sg == 0) launch_one<KS, 0, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, st);
-    else if (sg == 1) launch_one<KS, 1, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, st);
-    else launch_one<KS, 2, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, st);
+               bool o_vec, bool obf, hipStream_t st) {
+    if (sg == 0) launch_one<KS, 0, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
+    else if (sg == 1) launch_one<KS, 1, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
+    else launch_one<KS, 2, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
 }
 
 template <int KS, int MINW>
 void launch_shape(bool wide, const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld,
-                  int sg, bool o_vec, hipStream_t st) {
+                  int sg, bool o_vec, bool obf, hipStream_t st) {
     if constexpr (KS > 16) {
-        if (wide) return launch_ks<KS, 1, 8>(qp, B, O, N, c, out, ld, sg, o_vec, st);
+        if (wide) return launch_ks<KS, 1, 8>(qp, B, O, N, c, out, ld, sg, o_vec, obf, st);
     }
-    launch_ks<KS, MINW, 4>(qp, B, O, N, c, out, ld, sg, o_vec, st);
+    launch_ks<KS, MINW, 4>(qp, B, O, N, c, out, ld, sg, o_vec, obf, st);
 }
 
 }  // namespace
@@ -212,13 +245,16 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
     hipStream_t st = (hipStream_t)stream;
     const int ks = (c + 15) / 16;
     const int sg = !(flags & RTK_SCORE_SIGMOID) ? 0 : ((flags & RTK_SCORE_SIGMOID_FAST) ? 2 : 1);
+    const bool obf = (flags & RTK_SCORE_OUT_BF16) != 0;
+    RTK_REQUIRE(!obf || sg == 2, RTK_ERR_UNSUPPORTED, "rtk_score_packed_bf16: RTK_SCORE_OUT_BF16 needs RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST");
+    RTK_REQUIRE(!obf || (reinterpret_cast<uintptr_t>(out) & 3) == 0, RTK_ERR_BAD_ARG, "rtk_score_packed_bf16: bf16 out must be 4-byte aligned");
     const bool o_vec = (c % 8 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
     const unsigned char *qp = (const unsigned char *)q_packed;
     const rtk_bf16 *Ob = (const rtk_bf16 *)O;
     const int B = (int)batch, N = (int)n_local;
     // 8-wave workgroups (256 entities share a staged query tile) once the problem fills the chip that way
     const bool wide = ks > 16 && rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256;
-#define RTK_KS(K_, W_) case K_: launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, st); break;
+#define RTK_KS(K_, W_) case K_: launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, obf, st); break;
     switch (ks) {
         RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
         RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)

@@ -34,10 +34,12 @@ DEFAULT_SIGMOID = os.environ.get("R_TUCKER_AMD_SIGMOID", "fast")
 ROW_ALIGN = max(1, int(os.environ.get("R_TUCKER_AMD_ROW_ALIGN", "32")))
 
 
-def alloc_scores(B, N, device, lead=()):
-    """(lead..., B, N) float32 score buffer whose rows start on ROW_ALIGN-element boundaries."""
-    pitch = -(-N // ROW_ALIGN) * ROW_ALIGN
-    buf = torch.empty(tuple(lead) + (B, pitch), dtype=torch.float32, device=device)
+def alloc_scores(B, N, device, lead=(), dtype=torch.float32):
+    """(lead..., B, N) score buffer whose rows start on 128-byte boundaries (ROW_ALIGN float32
+    elements; twice as many bf16 ones)."""
+    unit = ROW_ALIGN * (4 // torch.empty((), dtype=dtype).element_size()) if ROW_ALIGN > 1 else 1
+    pitch = -(-N // unit) * unit
+    buf = torch.empty(tuple(lead) + (B, pitch), dtype=dtype, device=device)
     return buf[..., :N] if pitch != N else buf
 
 
@@ -84,7 +86,8 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None, out=None):
+def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None, out=None,
+             out_dtype=torch.float32):
     lib = _lib.load()
     _require_gpu("core", core)
     if core.dtype not in (torch.float32, torch.bfloat16):
@@ -109,11 +112,15 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
     if b != c:
         # asymmetric/R_TuckER.py:46: .view(-1, b) of a (B,1,c) tensor
         raise RuntimeError(f"shape '[-1, {b}]' is invalid for input of size {B * c}")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"out_dtype must be float32 or bfloat16, got {out_dtype}")
+    if out_dtype == torch.bfloat16 and (not bf16 or want_v or not sigmoid or exact):
+        raise RuntimeError("bfloat16 scores: bf16 operands, sigmoid=True, no autograd (the reference's bf16 eval path)")
     if out is None:
-        out = torch.empty((B, N), dtype=torch.float32, device=dev) if want_v else alloc_scores(B, N, dev)
-    elif (tuple(out.shape) != (B, N) or out.dtype != torch.float32 or out.device != dev or out.stride(1) != 1
+        out = torch.empty((B, N), dtype=torch.float32, device=dev) if want_v else alloc_scores(B, N, dev, dtype=out_dtype)
+    elif (tuple(out.shape) != (B, N) or out.dtype != out_dtype or out.device != dev or out.stride(1) != 1
           or out.stride(0) < N):
-        raise RuntimeError(f"out must be a float32 ({B}, {N}) tensor on {dev} with unit column stride")
+        raise RuntimeError(f"out must be a {out_dtype} ({B}, {N}) tensor on {dev} with unit column stride")
     ld = out.stride(0) if B > 1 else N
     if B == 0:
         return out, None
@@ -132,6 +139,10 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
             raise ValueError(f"sigmoid mode must be 'fast' or 'exact', got {mode!r}")
         flags = (_lib.RTK_SCORE_SIGMOID if sigmoid else 0) | (_lib.RTK_SCORE_EXACT_F32 if exact else 0)
         flags |= _lib.RTK_SCORE_SIGMOID_FAST if (sigmoid and mode == "fast") else 0
+        if out_dtype == torch.bfloat16:
+            if mode != "fast":
+                raise RuntimeError("bfloat16 scores use the fast logistic (sigmoid_mode='fast')")
+            flags |= _lib.RTK_SCORE_OUT_BF16
         sflags = flags & (_lib.RTK_SCORE_SIGMOID | _lib.RTK_SCORE_SIGMOID_FAST)
         v = None
         if want_v:
@@ -278,19 +289,26 @@ def bce_loss_1vN(core, R, S, O, subject_idx, relation_idx, flt, item_ids, label_
                              float(label_smoothing))
 
 
-def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=False, sigmoid_mode=None):
+def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=False, sigmoid_mode=None,
+              out_dtype=torch.float32):
     """``sigmoid((G x_0 R[r] x_1 S[h]) . O^T)`` for a batch of (h, r) queries -> ``(B, N)``.
 
     Same operands and result as the body of the reference's ``score_fn``
     (asymmetric/R_TuckER.py:43-48; symmetric: pass ``S is O``).  ``exact=True``
     selects the exact-fp32 MFMA score kernel instead of the split-fp16 one;
     ``sigmoid_mode`` ("fast" | "exact") picks the logistic of the fused epilogue.
+    ``out_dtype=torch.bfloat16`` (bf16 operands, no autograd): the scores are rounded to bf16 in the
+    kernel -- the dtype the reference's bf16 model returns -- which halves the dominant HBM traffic;
+    bit-identical to ``score_1vN(...).to(torch.bfloat16)``.
     """
     needs_grad = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (core, R, S, O))
     if needs_grad:
+        if out_dtype != torch.float32:
+            raise RuntimeError("bfloat16 scores are an inference option (no autograd)")
         return _Score1vN.apply(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, sigmoid_mode)
-    out, _ = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False, sigmoid_mode=sigmoid_mode)
+    out, _ = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False, sigmoid_mode=sigmoid_mode,
+                      out_dtype=out_dtype)
     return out
 
 

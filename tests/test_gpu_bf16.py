@@ -63,6 +63,30 @@ def test_bf16_scores_against_float64_of_bf16_params(rt, shape, sym):
     assert np.max(np.abs(p - 1 / (1 + np.exp(-ze)))) <= 0.25 * Z_TOL_BF16 * 2   # |dp| <= |dz| / 4
 
 
+@pytest.mark.parametrize("shape", [
+    (3000, 22, 96, (10, 200, 200)), (2001, 5, 70, (3, 24, 24)),       # even / odd entity count (last column alone)
+    (129, 3, 33, (2, 512, 512)), (1, 1, 1, (1, 8, 8)), (4097, 7, 300, (4, 272, 272)),
+])
+@pytest.mark.parametrize("dense", [False, True])
+def test_bf16_scores_written_as_bf16(rt, shape, dense, monkeypatch):
+    """out_dtype=bfloat16: the kernel rounds the probabilities itself (pairs of columns traded
+    between neighbouring lanes, v_cvt_pk_bf16_f32) -- bit-identical to rounding the fp32 scores,
+    with 128-byte aligned rows (default) and with the dense row pitch (odd N: unaligned pairs)."""
+    n_ent, n_rel, B, rank = shape
+    from r_tucker_amd import ops
+    monkeypatch.setattr(ops, "ROW_ALIGN", 1 if dense else 32)
+    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 33)
+    h, r = gen.make_queries(n_ent, n_rel, B, 33)
+    d = [bf16_round(x).cuda() for x in (core, R, S, O)]
+    hh, rr = torch.from_numpy(h).cuda(), torch.from_numpy(r).cuda()
+    p32 = rt.score_1vN(*d, hh, rr)
+    pb = rt.score_1vN(*d, hh, rr, out_dtype=torch.bfloat16)
+    assert pb.dtype == torch.bfloat16 and pb.shape == (B, n_ent)
+    assert torch.equal(pb, p32.to(torch.bfloat16))
+    with pytest.raises(RuntimeError):
+        rt.score_1vN(*d, hh, rr, sigmoid=False, out_dtype=torch.bfloat16)
+
+
 def test_bf16_closure_and_grad(rt):
     """model surface with bf16 parameters; gradients flow (computed in fp32, returned in bf16)."""
     n_ent, n_rel, B, rank = 400, 6, 20, (4, 16, 16)
