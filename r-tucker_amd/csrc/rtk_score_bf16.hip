@@ -253,7 +253,8 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
     const rtk_bf16 *Ob = (const rtk_bf16 *)O;
     const int B = (int)batch, N = (int)n_local;
     // 8-wave workgroups (256 entities share a staged query tile) once the problem fills the chip that way
-    const bool wide = ks > 16 && rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256;
+    static const bool narrow = getenv("RTK_BF16_NARROW") != nullptr;   // A/B: 4-wave workgroups, two per CU
+    const bool wide = !narrow && ks > 16 && rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256;
 #define RTK_KS(K_, W_) case K_: launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, obf, st); break;
     switch (ks) {
         RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
