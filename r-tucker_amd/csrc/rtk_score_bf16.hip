@@ -27,6 +27,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
     constexpr int CHUNKS = TILE_BYTES / 16;
     constexpr int NT = 64 * NW;               // threads
     constexpr int NLD = (CHUNKS + NT - 1) / NT;
+    static_assert(NLD <= KS, "one staging load per k-step of the chain");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * TILE_BYTES
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -64,12 +65,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
         }
 
         u32x4 stg[NLD];
+        auto stage_load_one = [&](int mt, int i) {
+            const unsigned vo = (i + 1 < NLD || i * NT + t < CHUNKS) ? (unsigned)(t * 16) : 0x80000000u;
+            stg[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, mt * TILE_BYTES + i * NT * 16, 0);
+        };
         auto stage_load = [&](int mt) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const unsigned vo = (i + 1 < NLD || i * NT + t < CHUNKS) ? (unsigned)(t * 16) : 0x80000000u;
-                stg[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, mt * TILE_BYTES + i * NT * 16, 0);
-            }
+            for (int i = 0; i < NLD; ++i) stage_load_one(mt, i);
         };
         auto stage_store = [&](int buf) {
             u32x4 *dst = reinterpret_cast<u32x4 *>(lds + buf * TILE_BYTES);
@@ -147,7 +149,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
         for (int e = 0; e < 16; ++e) prev[e] = 0.f;
         for (int i = 0; i < cnt; ++i) {
             const int cur = i & 1;
-            if (i + 1 < cnt) stage_load(mt0 + i + 1);
+            // One workgroup per CU (NW == 8): the next tile's staging loads are issued one per MFMA gap
+            // at the head of the chain, not in front of it -- 8 waves x NLD 1-KiB loads through one
+            // address unit hold the first MFMA back by several hundred cycles on every tile (C5: 1.27 ->
+            // 1.21 ms).  Two workgroups per CU (NW == 4) cover each other's gaps; there the early issue
+            // wins (C3: 32.5 vs 37 us).
+            constexpr bool STAGE_IN_CHAIN = NW == 8;
+            const bool stage = i + 1 < cnt;
+            if (!STAGE_IN_CHAIN && stage) stage_load(mt0 + i + 1);
             const bf16x8 *la = reinterpret_cast<const bf16x8 *>(lds + cur * TILE_BYTES + RTK_PACK_HDR);
             f32x16 acc, acc2;
 #pragma unroll
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
                 if (ks + PF < KS) fa[ks % PF] = la[(ks + PF) * 64 + lane];
                 if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bf[ks], acc2, 0, 0, 0);
                 else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bf[ks], acc, 0, 0, 0);
+                if (STAGE_IN_CHAIN && ks < NLD && stage) stage_load_one(mt0 + i + 1, ks);
 #pragma unroll
                 for (int pc = ks * 32 / KS; pc < (ks + 1) * 32 / KS; ++pc) piece(prev, pc);
                 __builtin_amdgcn_sched_barrier(0);
