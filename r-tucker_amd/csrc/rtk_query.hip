@@ -53,26 +53,36 @@ __global__ __launch_bounds__(1024) void plan_kernel(const int64_t *__restrict__ 
 // so it costs no launch.  The order inside a slot is arbitrary (atomic tickets); every query's
 // row is computed independently, so the result does not depend on it.
 constexpr int GROUPS_LDS_SLOTS = 2048;   // counters live in LDS up to this many slots (global atomics beyond)
-__device__ void build_groups(const int64_t *__restrict__ rel_idx, int B, int n_rel,
-                             const int32_t *__restrict__ slot_of_rel, int n_slots, int QG,
-                             int32_t *__restrict__ cnt_g, int32_t *__restrict__ order,
-                             int32_t *__restrict__ work, uint32_t *__restrict__ flags,
-                             const int64_t *__restrict__ sub_idx, int64_t *__restrict__ qinfo) {
-    __shared__ int sc_q[256], sc_w[256];
-    __shared__ int base_q, base_w;
-    __shared__ int cnt_l[2 * GROUPS_LDS_SLOTS];
+// CNT: pointer type of the counters -- an LDS array (ds_add_rtn: ~100 cycles a round) when the slots
+// fit, the workspace otherwise; as one generic pointer the atomics are flat_atomic_* for both and
+// the B = 8192 build took 50 us.
+template <typename CNT>
+__device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ rel_idx, int B, int n_rel,
+                                                  const int32_t *__restrict__ slot_of_rel, int n_slots, int QG,
+                                                  CNT cnt, int32_t *__restrict__ order,
+                                                  int32_t *__restrict__ work, uint32_t *__restrict__ flags,
+                                                  const int64_t *__restrict__ sub_idx, int64_t *__restrict__ qinfo,
+                                                  int *sc_q, int *sc_w, int &base_q, int &base_w) {
     const int t = threadIdx.x;
-    // one code path: the counters are either the LDS array or the workspace array (generic pointers)
-    int *cnt = n_slots <= GROUPS_LDS_SLOTS ? cnt_l : cnt_g;
-    int *fill = cnt + n_slots;
+    CNT fill = cnt + n_slots;
     for (int s = t; s < 2 * n_slots; s += 256) cnt[s] = 0;
     if (t == 0) { base_q = 0; base_w = 0; }
     __syncthreads();
-    for (int d = t; d < B; d += 256) {
-        int64_t r = rel_idx[d];
-        r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);   // bad ids are reported by the contract kernel
-        const int s = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
-        atomicAdd(&cnt[s], 1);
+    // (ids are fetched eight at a time ahead of the atomics: one workgroup walks the whole batch,
+    // a load per trip would be a chain of B / 256 exposed latencies)
+    constexpr int CH = 8;
+    for (int d0 = t; d0 < B; d0 += 256 * CH) {
+        int sl[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int d = d0 + 256 * k;
+            int64_t r = d < B ? rel_idx[d] : 0;
+            r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);   // bad ids are reported by the contract kernel
+            sl[k] = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (d0 + 256 * k < B) atomicAdd(&cnt[sl[k]], 1);
     }
     __syncthreads();
     // exclusive scans (queries, work items) over the slots, 256 at a time; fill[] := first position
@@ -106,17 +116,45 @@ __device__ void build_groups(const int64_t *__restrict__ rel_idx, int B, int n_r
         __syncthreads();
     }
     if (t == 0) flags[2] = (uint32_t)base_w;
-    for (int d = t; d < B; d += 256) {
-        int64_t r = rel_idx[d];
-        r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);
-        const int s = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
-        const int pos = atomicAdd(&fill[s], 1);
-        order[pos] = d;
-        if (qinfo) {   // what the per-query contract kernel needs about position pos, in one 16-B load
-            qinfo[2 * (int64_t)pos] = sub_idx[d];
-            qinfo[2 * (int64_t)pos + 1] = (int64_t)(uint32_t)d | ((int64_t)s << 32);
+    for (int d0 = t; d0 < B; d0 += 256 * CH) {
+        int sl[CH];
+        int64_t hs[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int d = d0 + 256 * k;
+            int64_t r = d < B ? rel_idx[d] : 0;
+            r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);
+            sl[k] = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+            hs[k] = (qinfo && d < B) ? sub_idx[d] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int d = d0 + 256 * k;
+            if (d >= B) continue;
+            const int pos = atomicAdd(&fill[sl[k]], 1);
+            order[pos] = d;
+            if (qinfo) {   // what the per-query contract kernel needs about position pos, in one 16-B load
+                qinfo[2 * (int64_t)pos] = hs[k];
+                qinfo[2 * (int64_t)pos + 1] = (int64_t)(uint32_t)d | ((int64_t)sl[k] << 32);
+            }
         }
     }
+}
+
+__device__ void build_groups(const int64_t *__restrict__ rel_idx, int B, int n_rel,
+                             const int32_t *__restrict__ slot_of_rel, int n_slots, int QG,
+                             int32_t *__restrict__ cnt_g, int32_t *__restrict__ order,
+                             int32_t *__restrict__ work, uint32_t *__restrict__ flags,
+                             const int64_t *__restrict__ sub_idx, int64_t *__restrict__ qinfo) {
+    __shared__ int sc_q[256], sc_w[256];
+    __shared__ int base_q, base_w;
+    __shared__ int cnt_l[2 * GROUPS_LDS_SLOTS];
+    if (n_slots <= GROUPS_LDS_SLOTS)
+        build_groups_impl<int *>(rel_idx, B, n_rel, slot_of_rel, n_slots, QG, (int *)cnt_l, order, work, flags, sub_idx, qinfo,
+                                 sc_q, sc_w, base_q, base_w);
+    else
+        build_groups_impl<int32_t *>(rel_idx, B, n_rel, slot_of_rel, n_slots, QG, cnt_g, order, work, flags, sub_idx, qinfo,
+                                     sc_q, sc_w, base_q, base_w);
 }
 
 struct GroupArgs {   // by value to the kernels that host the extra block
