@@ -18,7 +18,7 @@ namespace {
 // NW waves per workgroup, 32 entity rows each: the staged query tile is shared by 32*NW entities,
 // so its L2 -> CU traffic per score is 2*K / (32*NW) bytes (K = 512, NW = 4: 8 B per 4-B score).
 // QB = query tiles per block of the sweep: every workgroup walks the query blocks in the same
-// order, so the chip works on one block (QB tiles, <= ~1.5 MB) at a time and it stays in the L2s.
+// order, so the chip works on one block (QB tiles, <= ~3 MB) at a time and it stays in the L2s.
 template <int KS, int SIGMOID, int MINW, int NW, bool NTS, bool OBF>
 __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
     const unsigned char *__restrict__ q_packed, int B, const rtk_bf16 *__restrict__ O, int N, int c,
@@ -200,7 +200,10 @@ void launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, 
         attr_set = true;
     }
     const int n_mt = (int)rtk_cdiv(B, 32);
-    int qb = (int)((3 << 19) / tile);          // query tiles per block of the sweep: <= 1.5 MB of packed planes
+    static const int qb_kb = getenv("RTK_BF16_QB_KB") ? atoi(getenv("RTK_BF16_QB_KB")) : 3072;   // A/B: block size of the sweep
+    // query tiles per block of the sweep: <= 3 MB of packed planes (C5 shard, score kernel: 0.5 MB 1.47 ms,
+    // 1 MB 1.29, 1.5 MB 1.20, 2.5-6 MB 1.15-1.17, unblocked 1.18 -- small blocks reload the B fragments too often)
+    if (qb < 1) qb = 1;
     if (qb >= n_mt) qb = n_mt;
     else qb = (int)rtk_cdiv(n_mt, rtk_cdiv(n_mt, qb));   // equal blocks
     const int64_t units = rtk_cdiv(N, 32 * NW) * (int64_t)qb;
