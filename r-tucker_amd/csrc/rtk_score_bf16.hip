@@ -203,6 +203,7 @@ void launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, 
     static const int qb_kb = getenv("RTK_BF16_QB_KB") ? atoi(getenv("RTK_BF16_QB_KB")) : 3072;   // A/B: block size of the sweep
     // query tiles per block of the sweep: <= 3 MB of packed planes (C5 shard, score kernel: 0.5 MB 1.47 ms,
     // 1 MB 1.29, 1.5 MB 1.20, 2.5-6 MB 1.15-1.17, unblocked 1.18 -- small blocks reload the B fragments too often)
+    int qb = (int)(((size_t)qb_kb << 10) / tile);
     if (qb < 1) qb = 1;
     if (qb >= n_mt) qb = n_mt;
     else qb = (int)rtk_cdiv(n_mt, rtk_cdiv(n_mt, qb));   // equal blocks
