@@ -73,7 +73,7 @@ static int kernel_choice() {
 
 int rtk_split_ksteps_supported(int c) {
     const int ks = (c + 15) / 16;
-    return ks >= 1 && ks <= 16;   // two fp16 planes of B fragments must fit the register file next to the pipeline state
+    return ks >= 1 && ks <= 32;   // two fp16 planes of B fragments must fit the register file next to the pipeline state
 }
 
 extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, const float *O,
@@ -84,7 +84,7 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
     RTK_REQUIRE(ld_out >= n_local, RTK_ERR_BAD_ARG, "rtk_score_packed_f32: ld_out < n_local");
     RTK_REQUIRE(ld_out < (1ll << 24), RTK_ERR_UNSUPPORTED, "rtk_score_packed_f32: ld_out >= 2^24 (32 rows must fit a 2 GiB buffer window)");
     RTK_REQUIRE(batch < (1ll << 31) && n_local < (1ll << 31) - 256, RTK_ERR_UNSUPPORTED, "rtk_score_packed_f32: dimension too large");
-    RTK_REQUIRE(rtk_split_ksteps_supported(c), RTK_ERR_UNSUPPORTED, "rtk_score_packed_f32: c=%d > 256 not supported by the split-fp16 kernel (use rtk_score_f32)", c);
+    RTK_REQUIRE(rtk_split_ksteps_supported(c), RTK_ERR_UNSUPPORTED, "rtk_score_packed_f32: c=%d > 512 not supported by the split-fp16 kernel (use rtk_score_f32)", c);
     hipStream_t st = (hipStream_t)stream;
     const int ks = (c + 15) / 16;
     const int sg = !(flags & RTK_SCORE_SIGMOID) ? 0 : ((flags & RTK_SCORE_SIGMOID_FAST) ? 2 : 1);
@@ -102,6 +102,11 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
     switch (ks) {
         RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
         RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)
+        // 256 < c <= 512 (the doubled-rank tensors the Riemannian gradient scores): one
+        // 4-wave workgroup per CU, the hi/lo B fragments take up to 256 of a wave's 512 registers
+        // (the compiler places them in the accumulation half of the unified file)
+        RTK_KS(17, 1) RTK_KS(18, 1) RTK_KS(19, 1) RTK_KS(20, 1) RTK_KS(21, 1) RTK_KS(22, 1) RTK_KS(23, 1) RTK_KS(24, 1)
+        RTK_KS(25, 1) RTK_KS(26, 1) RTK_KS(27, 1) RTK_KS(28, 1) RTK_KS(29, 1) RTK_KS(30, 1) RTK_KS(31, 1) RTK_KS(32, 1)
         default:
             rtk_set_error("rtk_score_packed_f32: unsupported k-step count %d", ks);
             return RTK_ERR_UNSUPPORTED;

@@ -148,7 +148,7 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
         if want_v:
             # two-call form so the fp32 query vectors are kept for backward
             v = torch.empty((B, c), dtype=torch.float32, device=dev)
-            use_packed = bf16 or (not exact and c <= 256)
+            use_packed = bf16 or (not exact and c <= 512)
             qp = None
             if use_packed:
                 qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev)

@@ -120,6 +120,7 @@ def test_full_size_against_reference_samples(rt, golden, golden_meta, name):
     (1, 1, 1, (1, 1, 1)), (129, 3, 33, (2, 20, 20)), (257, 5, 1, (3, 10, 10)), (1000, 40, 64, (7, 36, 36)),
     (300, 700, 50, (40, 24, 24)),       # n_rel > batch -> device-side relation plan; a > 32 -> MFMA tables
     (4100, 11, 260, (5, 64, 64)), (513, 9, 97, (4, 7, 7)),  # c % 4 != 0 -> scalar load paths
+    (1500, 9, 70, (3, 272, 272)), (900, 5, 33, (2, 400, 400)), (700, 4, 40, (2, 512, 512)),  # 256 < c <= 512: one workgroup per CU
 ])
 @pytest.mark.parametrize("exact", [False, True])
 def test_ragged_shapes_against_oracle(rt, shape, exact):
