@@ -12,7 +12,9 @@
 
 namespace {
 
-__device__ __forceinline__ float clog(float x) { return fmaxf(logf(x), -100.0f); }   // torch clamps BCE's logs at -100
+// ln x on v_log_f32 (log2, 1 ulp) -- the row sums are compute-bound on ocml's logf otherwise (62 us vs the
+// 15 us the 84 MB read takes at C2); torch clamps BCE's logs at -100
+__device__ __forceinline__ float clog(float x) { return fmaxf(__builtin_amdgcn_logf(x) * 0.6931471805599453f, -100.0f); }
 
 // one workgroup per row
 __global__ __launch_bounds__(256) void bce_rows_kernel(const float *__restrict__ P, int N, int64_t ld, float t0, float dt,
@@ -25,7 +27,16 @@ __global__ __launch_bounds__(256) void bce_rows_kernel(const float *__restrict__
     const float *row = P + (int64_t)d * ld;
     // every entity as a smoothed negative: y = t0 = eps / N
     float acc = 0.f;
-    for (int j = t; j < N; j += 256) {
+    constexpr int U = 8;                               // loads in flight per thread (the pass is latency-bound otherwise)
+    int j = t;
+    for (; j + 256 * (U - 1) < N; j += 256 * U) {
+        float p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = row[j + 256 * u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += t0 * clog(p[u]) + (1.0f - t0) * clog(1.0f - p[u]);
+    }
+    for (; j < N; j += 256) {
         const float p = row[j];
         acc += t0 * clog(p) + (1.0f - t0) * clog(1.0f - p);
     }

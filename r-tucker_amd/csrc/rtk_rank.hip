@@ -19,6 +19,9 @@
 
 namespace {
 
+// ln x on v_log_f32 (log2, 1 ulp); torch clamps BCE's logs at -100
+__device__ __forceinline__ float clog(float x) { return fmaxf(__builtin_amdgcn_logf(x) * 0.6931471805599453f, -100.0f); }
+
 // PARTIAL: target scores come from pt_in, the "+1" is left to the caller, ids are global
 template <bool PARTIAL>
 __global__ __launch_bounds__(256) void filtered_rank_kernel(
@@ -37,11 +40,24 @@ __global__ __launch_bounds__(256) void filtered_rank_kernel(
     int gt = 0, eq = 0;
     float bce = 0.f;
     const bool want_bce = bce_rows != nullptr;
-    for (int j = t; j < N; j += 256) {
+    constexpr int U = 8;                               // loads in flight per thread (the pass is latency-bound otherwise)
+    int j = t;
+    for (; j + 256 * (U - 1) < N; j += 256 * U) {
+        float p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = row[j + 256 * u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            gt += p[u] > pt;
+            eq += (p[u] == pt) & (j + 256 * u < tgt);
+            if (want_bce) bce += clog(1.0f - p[u]);
+        }
+    }
+    for (; j < N; j += 256) {
         const float p = row[j];
         gt += p > pt;
         eq += (p == pt) & (j < tgt);
-        if (want_bce) bce += fmaxf(logf(1.0f - p), -100.0f);
+        if (want_bce) bce += clog(1.0f - p);
     }
     // the query's other true objects count as score 0 (and, for BCE, as positives)
     const int64_t s = pair_slot ? pair_slot[d] : -1;
@@ -50,14 +66,14 @@ __global__ __launch_bounds__(256) void filtered_rank_kernel(
             const int64_t j = pair_obj[i] - col0;
             if (j < 0 || j >= N) continue;
             const float p = row[j];
-            if (want_bce) bce += fmaxf(logf(p), -100.0f) - fmaxf(logf(1.0f - p), -100.0f);
+            if (want_bce) bce += clog(p) - clog(1.0f - p);
             if (j == tgt) continue;
             gt -= p > pt;
             eq -= (p == pt) & (j < tgt);
             eq += (0.0f == pt) & (j < tgt);     // now a 0: ties only with a zero target score
         }
     } else if (want_bce && t == 0 && own) {     // no filter list: the queried object is the only positive
-        bce += fmaxf(logf(pt), -100.0f) - fmaxf(logf(1.0f - pt), -100.0f);
+        bce += clog(pt) - clog(1.0f - pt);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
