@@ -266,20 +266,44 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
 // then K-contiguous, which is what the MFMA fragments want.
 __global__ __launch_bounds__(256) void transpose_core_kernel(const rtk_bf16 *__restrict__ G, int a, int64_t bc,
                                                              rtk_bf16 *__restrict__ GT) {
-    __shared__ rtk_bf16 tile[64][66];
+    // 64 (a) x 64 (n) tile through LDS; 8-byte accesses on both sides when the shapes allow (4 elements
+    // along n on the way in, 4 along a on the way out): a wave instruction then moves 512 B, not 128
+    __shared__ rtk_bf16 tile[64][68];
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
     const int64_t n0 = (int64_t)blockIdx.x * 64;
     const int a0 = blockIdx.y * 64;
     const int t = threadIdx.x;
-    for (int i = t; i < 64 * 64; i += 256) {      // rows of G (fixed a), 64 consecutive n: coalesced
-        const int ai = i >> 6, ni = i & 63;
-        rtk_bf16 x = 0;
-        if (a0 + ai < a && n0 + ni < bc) x = G[(int64_t)(a0 + ai) * bc + n0 + ni];
-        tile[ai][ni] = x;
+    const bool vin = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(G) & 7) == 0);
+    const bool vout = (a % 4 == 0) && ((reinterpret_cast<uintptr_t>(GT) & 7) == 0);
+    if (vin) {
+        for (int i = t; i < 64 * 16; i += 256) {      // rows of G (fixed a), 4 consecutive n per thread
+            const int ai = i >> 4, ni = (i & 15) * 4;
+            u16x4 x = {0, 0, 0, 0};
+            if (a0 + ai < a && n0 + ni < bc) x = *reinterpret_cast<const u16x4 *>(G + (int64_t)(a0 + ai) * bc + n0 + ni);
+            *reinterpret_cast<u16x4 *>(&tile[ai][ni]) = x;      // (bc % 4 == 0: a quad is wholly inside or outside)
+        }
+    } else {
+        for (int i = t; i < 64 * 64; i += 256) {
+            const int ai = i >> 6, ni = i & 63;
+            rtk_bf16 x = 0;
+            if (a0 + ai < a && n0 + ni < bc) x = G[(int64_t)(a0 + ai) * bc + n0 + ni];
+            tile[ai][ni] = x;
+        }
     }
     __syncthreads();
-    for (int i = t; i < 64 * 64; i += 256) {      // rows of GT (fixed n), 64 consecutive a: coalesced
-        const int ni = i >> 6, ai = i & 63;
-        if (a0 + ai < a && n0 + ni < bc) GT[(n0 + ni) * a + a0 + ai] = tile[ai][ni];
+    if (vout) {
+        for (int i = t; i < 64 * 16; i += 256) {      // rows of GT (fixed n), 4 consecutive a per thread
+            const int ni = i >> 4, ai = (i & 15) * 4;
+            if (a0 + ai < a && n0 + ni < bc) {
+                const u16x4 x = {tile[ai][ni], tile[ai + 1][ni], tile[ai + 2][ni], tile[ai + 3][ni]};
+                *reinterpret_cast<u16x4 *>(GT + (n0 + ni) * a + a0 + ai) = x;
+            }
+        }
+    } else {
+        for (int i = t; i < 64 * 64; i += 256) {
+            const int ni = i >> 6, ai = i & 63;
+            if (a0 + ai < a && n0 + ni < bc) GT[(n0 + ni) * a + a0 + ai] = tile[ai][ni];
+        }
     }
 }
 
