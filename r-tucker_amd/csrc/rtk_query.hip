@@ -90,16 +90,20 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
         const int s = s0 + t;
         const int nq = s < n_slots ? cnt[s] : 0;
         const int nw = (nq + QG - 1) / QG;
-        sc_q[t] = nq;
-        sc_w[t] = nw;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const int aq = t >= o ? sc_q[t - o] : 0, aw = t >= o ? sc_w[t - o] : 0;
-            __syncthreads();
-            sc_q[t] += aq;
-            sc_w[t] += aw;
-            __syncthreads();
+        // inclusive scans of (nq, nw) over the 256 slots of this chunk: shuffles inside a wave, the four
+        // wave totals through LDS (two barriers instead of the sixteen of a step-by-step LDS scan)
+        int iq = nq, iw = nw;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int uq = __shfl_up(iq, o), uw = __shfl_up(iw, o);
+            if ((t & 63) >= o) { iq += uq; iw += uw; }
         }
+        if ((t & 63) == 63) { sc_q[t >> 6] = iq; sc_w[t >> 6] = iw; }
+        __syncthreads();
+        for (int w = 0; w < (t >> 6); ++w) { iq += sc_q[w]; iw += sc_w[w]; }
+        __syncthreads();
+        sc_q[t] = iq;
+        sc_w[t] = iw;
         const int q0 = base_q + sc_q[t] - nq, w0 = base_w + sc_w[t] - nw;
         if (s < n_slots) {
             fill[s] = q0;
