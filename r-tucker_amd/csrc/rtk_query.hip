@@ -69,7 +69,8 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
     if (t == 0) { base_q = 0; base_w = 0; }
     __syncthreads();
     // (ids are fetched eight at a time ahead of the atomics: one workgroup walks the whole batch,
-    // a load per trip would be a chain of B / 256 exposed latencies)
+    // a load per trip would be a chain of B / 256 exposed latencies; 32 at a time costs the HOST
+    // kernel 280 registers and its occupancy -- tables 5.5 -> 11 us)
     constexpr int CH = 8;
     for (int d0 = t; d0 < B; d0 += 256 * CH) {
         int sl[CH];
@@ -269,12 +270,19 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
 // K = a) and the core, transposed to [(b,c)][a], plays the entity matrix -- both operands are
 // then K-contiguous, which is what the MFMA fragments want.
 __global__ __launch_bounds__(256) void transpose_core_kernel(const rtk_bf16 *__restrict__ G, int a, int64_t bc,
-                                                             rtk_bf16 *__restrict__ GT) {
+                                                             rtk_bf16 *__restrict__ GT, GroupArgs ga) {
+    const int xb = ga.QG > 0 ? 1 : 0;
+    if (xb && blockIdx.x == 0) {   // the extra block: query groups for the contract kernel -- block 0, so that it
+        // is dispatched first and runs beside the whole transpose (a single workgroup's latency chain,
+        // longer than any tile); here, not in the small kernel that packs the relation rows
+        if (blockIdx.y == 0) build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
+        return;
+    }
     // 64 (a) x 64 (n) tile through LDS; 8-byte accesses on both sides when the shapes allow (4 elements
     // along n on the way in, 4 along a on the way out): a wave instruction then moves 512 B, not 128
     __shared__ rtk_bf16 tile[64][68];
     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int64_t n0 = (int64_t)(blockIdx.x - xb) * 64;
     const int a0 = blockIdx.y * 64;
     const int t = threadIdx.x;
     const bool vin = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(G) & 7) == 0);
@@ -314,12 +322,7 @@ __global__ __launch_bounds__(256) void transpose_core_kernel(const rtk_bf16 *__r
 __global__ __launch_bounds__(256) void pack_rel_rows_kernel(const rtk_bf16 *__restrict__ R, int a, int n_rel,
                                                             const int32_t *__restrict__ rel_list, int n_u_max,
                                                             const uint32_t *__restrict__ n_u_dev,
-                                                            unsigned char *__restrict__ planes, int ksteps,
-                                                            GroupArgs ga) {
-    if (ga.QG > 0 && blockIdx.x == gridDim.x - 1) {   // the extra block: query groups for the contract kernel
-        build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
-        return;
-    }
+                                                            unsigned char *__restrict__ planes, int ksteps) {
     const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
     const int u = blockIdx.x;                      // one relation slot per block (rows >= n_u: zeros)
     unsigned char *tile = planes + (int64_t)(u >> 5) * rtk_pack_tile_bytes(ksteps, 1);
@@ -675,11 +678,11 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
         // bf16, a <= 512: transpose the core, pack the relation rows, run the bf16 MFMA score kernel
         // with (queries, entities, K) := (relation slots, (b,c) pairs, a); raw fp32 output = the tables
         const int ks_a = (a + 15) / 16;
-        dim3 tg((unsigned)rtk_cdiv(bc, 64), (unsigned)rtk_cdiv(a, 64));
-        hipLaunchKernelGGL(transpose_core_kernel, tg, dim3(256), 0, st, (const rtk_bf16 *)core, a, bc, (rtk_bf16 *)ws.core_t);
+        dim3 tg((unsigned)rtk_cdiv(bc, 64) + xb, (unsigned)rtk_cdiv(a, 64));
+        hipLaunchKernelGGL(transpose_core_kernel, tg, dim3(256), 0, st, (const rtk_bf16 *)core, a, bc, (rtk_bf16 *)ws.core_t, ga);
         const int rows_padded = (int)rtk_cdiv(n_u_max, 32) * 32;
-        hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded + xb), dim3(256), 0, st, (const rtk_bf16 *)R, a,
-                           (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)ws.r_packed, ks_a, ga);
+        hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded), dim3(256), 0, st, (const rtk_bf16 *)R, a,
+                           (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)ws.r_packed, ks_a);
         int rc = rtk_score_packed_bf16(ws.r_packed, n_u_max, a, ws.core_t, bc, ws.tables, bc, 0, (void *)st);
         if (rc != RTK_OK) return rc;
     } else {
