@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
                                                      const uint32_t *__restrict__ n_u_dev,
                                                      float *__restrict__ M, GroupArgs ga) {
     __shared__ float Rs[UT * 64];  // UT relations x a (a <= 64 here)
-    if (ga.QG > 0 && blockIdx.x == gridDim.x - 1) {   // the extra block: query groups for the contract kernel
+    const int xb = ga.QG > 0 ? 1 : 0;
+    if (xb && blockIdx.x == 0) {   // the extra block (dispatched first): query groups for the contract kernel
         if (blockIdx.y == 0) build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
         return;
     }
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
     const int t = threadIdx.x;
     constexpr int W = VEC ? 4 : 1;
     constexpr int AB = 16;
-    const int64_t n = ((int64_t)blockIdx.x * 256 + t) * W;
+    const int64_t n = ((int64_t)(blockIdx.x - xb) * 256 + t) * W;
     const bool live = n < bc;
     // the first AB relation-rank slices of G are requested before anything else: they do not depend
     // on the R rows, whose trip through LDS (load, store, barrier) would otherwise sit in front of
