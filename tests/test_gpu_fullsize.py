@@ -99,6 +99,14 @@ def test_c5_shard_bf16_full_size_properties(rt):
     # shard consistency (bit-exact): a 3000-row sub-block
     zs = rt.score_1vN(core, R, S, O[50000:53000].contiguous(), h, r, sigmoid=False)
     assert torch.equal(zs, z[:, 50000:53000])
+    # probabilities written as bf16 by the 8-wave kernel = the fp32 probabilities rounded
+    del zs
+    p32 = rt.score_1vN(core, R, S, O, h, r)
+    pb = rt.score_1vN(core, R, S, O, h, r, out_dtype=torch.bfloat16)
+    assert pb.dtype == torch.bfloat16 and pb.shape == p32.shape
+    for lo in range(0, B, 1024):                       # in slices: the comparison needs a rounded copy
+        assert torch.equal(pb[lo:lo + 1024], p32[lo:lo + 1024].to(torch.bfloat16))
+    del p32, pb
     # sampled entries vs float64 of the same bf16 parameters
     qs = torch.tensor([0, 1, 4095, 8191], device="cuda")
     es = torch.tensor([0, 31, 64000, 124999], device="cuda")
@@ -106,5 +114,5 @@ def test_c5_shard_bf16_full_size_properties(rt):
                           O[es].float().cpu().numpy(), h[qs].cpu().numpy(), r[qs].cpu().numpy())
     zg = z[qs][:, es].cpu().numpy()
     assert np.max(np.abs(zg - ze) / (1 + np.abs(ze))) <= 5e-2
-    del z, zs
+    del z
     torch.cuda.empty_cache()
