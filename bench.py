@@ -81,8 +81,8 @@ def cpu_baseline(n_ent, n_rel, B, rank, pool, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="wn18rr_asym_r10x200_b512_f32", choices=sorted(WORKLOADS))
     ap.add_argument("--exact", action="store_true", help="exact-fp32 MFMA score kernel instead of split-fp16")
     ap.add_argument("--sigmoid", default=None, choices=["fast", "exact"], help="logistic of the fused epilogue (default: package default)")
