@@ -314,13 +314,16 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
     bool more;
     while (sc.next(ntile, mt0, cnt, more, next_tile)) {
         const int j = ntile * 128 + w4 * 32 + r;     // entity: row of O, column of out
+        // first query tile of the sweep: requested BEFORE the O tile goes to LDS, so its L2 round trip
+        // runs beside that write and the S1 wait instead of after them (it took longer than the M
+        // waves' conversion and held S2 back)
+        stage_load(mt0);
 #pragma unroll
         for (int i = 0; i < NOR; ++i) {
             const int pc = i * 256 + ht;
             if (pc < 32 * c) reinterpret_cast<u32x4 *>(oreg)[pc] = oraw[i];
         }
         __syncthreads();                             // S1
-        stage_load(mt0);                             // first query tile of the sweep (the M waves are busy converting)
         stage_store(0);
         if (more) load_oraw(next_tile);              // stays in registers for the whole sweep
         __syncthreads();                             // S2
