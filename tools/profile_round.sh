@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 declare -A W=( [c2]=wn18rr_asym_r10x200_b512_f32 [c3]=fb15k237_sym_r200x200_b2048_bf16 [c5]=synthetic1m_shard125k_r256x512_b8192_bf16 )
-declare -A STEPS=( [c2]=200 [c3]=100 [c5]=30 )
+declare -A STEPS=( [c2]=2000 [c3]=1000 [c5]=100 )
 for k in c2 c3 c5; do
   timeout -k 10 300 python3 $ROOT/bench.py --workload ${W[$k]} --steps ${STEPS[$k]} --warmup 10 > $OUT/${k}_bench.json 2> $OUT/${k}_bench.err
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${k}_trace -o p -- python3 $ROOT/bench.py --workload ${W[$k]} --steps ${STEPS[$k]} --warmup 10 --no-cpu-baseline > $OUT/${k}_prof_bench.json 2> $OUT/${k}_prof.err
