@@ -47,23 +47,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
         lin += cnt;
         const int j = ntile * 32 * NW + wave * 32 + r;  // entity (row of O, column of out)
 
-        // B fragments: lane (r, h) holds k = 16*ks + 8*h + q, q < 8 of row j = 16 contiguous bytes
-        const rtk_bf16 *orow = O + (int64_t)min(j, N - 1) * c;
-        bf16x8 Bf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = 16 * ks + 8 * h;
-            bf16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (o_vec) {  // c % 8 == 0: a fragment is wholly inside or wholly outside the row
-                if (k + 8 <= c) x = *reinterpret_cast<const bf16x8 *>(orow + k);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (k + q < c) x[q] = (short)orow[k + q];
-            }
-            Bf[ks] = x;
-        }
-
         u32x4 stg[NLD];
         auto stage_load_one = [&](int mt, int i) {
             const unsigned vo = (i + 1 < NLD || i * NT + t < CHUNKS) ? (unsigned)(t * 16) : 0x80000000u;
@@ -81,6 +64,26 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
                 if (i + 1 < NLD || ch < CHUNKS) dst[ch] = stg[i];
             }
         };
+        // first query tile of the unit: requested ahead of the B fragments (its L2 round trip then runs
+        // beside their loads instead of between the two barriers below)
+        stage_load(mt0);
+        // B fragments: lane (r, h) holds k = 16*ks + 8*h + q, q < 8 of row j = 16 contiguous bytes
+        const rtk_bf16 *orow = O + (int64_t)min(j, N - 1) * c;
+        bf16x8 Bf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 16 * ks + 8 * h;
+            bf16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (o_vec) {  // c % 8 == 0: a fragment is wholly inside or wholly outside the row
+                if (k + 8 <= c) x = *reinterpret_cast<const bf16x8 *>(orow + k);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k + q < c) x[q] = (short)orow[k + q];
+            }
+            Bf[ks] = x;
+        }
+
         // OBF: bf16 scores (what the reference's bf16 model returns).  Adjacent lanes (columns j, j + 1)
         // trade one value per row pair through DPP so that each holds two neighbouring columns of ONE
         // row, rounds them with v_cvt_pk_bf16_f32 and stores 4 bytes: the even lane the pair's first
@@ -141,7 +144,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
         };
 
         __syncthreads();   // previous unit's last tile fully read before restaging buffer 0
-        stage_load(mt0);
         stage_store(0);
         __syncthreads();
         f32x16 prev;
