@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--out-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 workloads: dtype of the score matrix (bf16 = what the reference's bf16 model returns)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the multi-GPU code path (process group, collectives) with however many ranks there are, even one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,7 +100,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=3))
 
@@ -160,7 +163,7 @@ def main():
 
     def step(i, ev=None):
         step_local(i, ev)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))   # in place: input = own slot
             if ev:
                 ev[2].record(stream)
@@ -183,7 +186,7 @@ def main():
             ev[1].record(stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -199,14 +202,14 @@ def main():
         step(args.warmup + i, events[i])
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     events = [e for e in events if e is not None]
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if world > 1 else None
+    gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if use_dist else None
     # algorithmic bytes of ONE score-kernel launch: read the O shard once, write the scores once,
     # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
     alg_bytes = n_loc * c * esz + B * n_loc * osz + B * c * esz
@@ -234,7 +237,7 @@ def main():
                      "kernel": ("score_bf16_kernel" if bf16 else "score_ws_kernel") if not args.exact else "gemm_f32_kernel",
                      "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
     }
-    if world > 1:
+    if use_dist:
         # the exchange step: every rank receives (P-1) blocks of B*n_loc fp32 over xGMI
         # (7 links x ~153 GB/s per GPU, MI355X guide); reported next to the shard-local rate
         recv = (world - 1) * B * pitch * osz
@@ -242,7 +245,7 @@ def main():
                               "bytes_received_per_gpu": recv, "achieved_GBps": recv / (gather_ms * 1e-3) / 1e9,
                               "xgmi_peak_GBps": 7 * 153.0, "frac": recv / (gather_ms * 1e-3) / 1e9 / (7 * 153.0),
                               "shard_local_queries_per_s": B / (kern_ms * 1e-3)}
-    if world > 1:
+    if use_dist:
         # The same scores consumed shard-locally: filtered rank of a queried object per
         # query with NO gather -- two all-reduces of B words instead of (P-1)*B*n_loc*4 bytes.
         try:
@@ -286,7 +289,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(n_ent, n_rel, B, trank, pool_cpu)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
