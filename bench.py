@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--out-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 workloads: dtype of the score matrix (bf16 = what the reference's bf16 model returns)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="multi-GPU: run the all-gather of step i before step i+1 starts (default: it overlaps the next step's kernels)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-GPU code path (process group, collectives) with however many ranks there are, even one")
     args = ap.parse_args()
@@ -146,10 +148,14 @@ def main():
     osz = 2 if obf else 4
     ra = _ops.ROW_ALIGN * (4 // osz) if _ops.ROW_ALIGN > 1 else 1
     pitch = -(-n_loc // ra) * ra
-    gathered = torch.empty((world, B, pitch), dtype=torch.bfloat16 if obf else torch.float32, device=dev)
+    # two gather buffers: the all-gather of step i (RCCL's own stream) overlaps the kernels of step i+1
+    n_buf = 2 if (use_dist and not args.no_overlap) else 1
+    gathered_all = [torch.empty((world, B, pitch), dtype=torch.bfloat16 if obf else torch.float32, device=dev)
+                    for _ in range(n_buf)]
     if obf:
         sflags |= _lib.RTK_SCORE_OUT_BF16
-    out = gathered[rank]
+    gathered, out = gathered_all[0], gathered_all[0][rank]
+    pending = [None] * n_buf
 
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
@@ -162,13 +168,26 @@ def main():
     v = torch.empty((B, c), dtype=torch.float32, device=dev)
 
     def step(i, ev=None):
-        step_local(i, ev)
+        k = i % n_buf
+        if pending[k] is not None:          # the gather that last used this buffer must be done before it is rewritten
+            pending[k].wait()
+            pending[k] = None
+        g = gathered_all[k]
+        step_local(i, ev, g[rank])
         if use_dist:
-            dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))   # in place: input = own slot
-            if ev:
-                ev[2].record(stream)
+            # in place: the input is this rank's slot of the output
+            if n_buf == 1:
+                dist.all_gather_into_tensor(g.view(-1), g[rank].view(-1))
+            else:
+                pending[k] = dist.all_gather_into_tensor(g.view(-1), g[rank].view(-1), async_op=True)
 
-    def step_local(i, ev=None):
+    def drain():
+        for k in range(n_buf):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+
+    def step_local(i, ev=None, out=out):
         h, r = pool[i % len(pool)]
         _lib.check(qv_fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent,
                                              r.data_ptr(), h.data_ptr(), B, v.data_ptr() if args.exact else None,
@@ -186,6 +205,7 @@ def main():
             ev[1].record(stream)
 
     def barrier():
+        drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -209,7 +229,15 @@ def main():
 
     events = [e for e in events if e is not None]
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if use_dist else None
+    gather_ms = None
+    if use_dist:      # the exchange on its own (in the timed loop it runs beside the next step's kernels)
+        ge = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(10)]
+        for e0, e1 in ge:
+            e0.record(stream)
+            dist.all_gather_into_tensor(gathered.view(-1), out.view(-1))
+            e1.record(stream)
+        barrier()
+        gather_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ge]))
     # algorithmic bytes of ONE score-kernel launch: read the O shard once, write the scores once,
     # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
     alg_bytes = n_loc * c * esz + B * n_loc * osz + B * c * esz
@@ -242,6 +270,7 @@ def main():
         # (7 links x ~153 GB/s per GPU, MI355X guide); reported next to the shard-local rate
         recv = (world - 1) * B * pitch * osz
         result["exchange"] = {"collective": "all_gather_into_tensor (RCCL, in place)", "ms": gather_ms,
+                              "overlapped_with_next_step": n_buf == 2,
                               "bytes_received_per_gpu": recv, "achieved_GBps": recv / (gather_ms * 1e-3) / 1e9,
                               "xgmi_peak_GBps": 7 * 153.0, "frac": recv / (gather_ms * 1e-3) / 1e9 / (7 * 153.0),
                               "shard_local_queries_per_s": B / (kern_ms * 1e-3)}
