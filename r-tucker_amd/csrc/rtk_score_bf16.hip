@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = acc2[e] = 0.f;
             epilogue_begin(mt0 + i - 1, i > 0);
-            constexpr int PF = KS < 3 ? KS : 3;
+            constexpr int PF = KS < 4 ? KS : (NW == 8 ? 4 : 3);
             bf16x8 fa[PF];
 #pragma unroll
             for (int p = 0; p < PF; ++p) fa[p] = la[p * 64 + lane];
