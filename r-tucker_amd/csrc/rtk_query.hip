@@ -72,6 +72,11 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
     // a load per trip would be a chain of B / 256 exposed latencies; 32 at a time costs the HOST
     // kernel 280 registers and its occupancy -- tables 5.5 -> 11 us)
     constexpr int CH = 8;
+    // batches of up to 256 * CH queries: slots and subject ids are read ONCE and kept in registers
+    // across the scan (the scatter pass then has no load round trip of its own)
+    const bool single = B <= 256 * CH;
+    int sl1[CH];
+    int64_t hs1[CH];
     for (int d0 = t; d0 < B; d0 += 256 * CH) {
         int sl[CH];
 #pragma unroll
@@ -80,6 +85,10 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
             int64_t r = d < B ? rel_idx[d] : 0;
             r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);   // bad ids are reported by the contract kernel
             sl[k] = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+            if (single) {
+                sl1[k] = sl[k];
+                hs1[k] = (qinfo && d < B) ? sub_idx[d] : 0;
+            }
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k)
@@ -127,10 +136,15 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int d = d0 + 256 * k;
-            int64_t r = d < B ? rel_idx[d] : 0;
-            r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);
-            sl[k] = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
-            hs[k] = (qinfo && d < B) ? sub_idx[d] : 0;
+            if (single) {
+                sl[k] = sl1[k];
+                hs[k] = hs1[k];
+            } else {
+                int64_t r = d < B ? rel_idx[d] : 0;
+                r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);
+                sl[k] = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
+                hs[k] = (qinfo && d < B) ? sub_idx[d] : 0;
+            }
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
