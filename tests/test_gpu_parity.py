@@ -163,6 +163,31 @@ def test_grouped_contract_rows_equal_per_query_rows(rt, shape):
     rt.check_device_errors()
 
 
+def test_padded_row_pitch_is_transparent_to_the_callers_ops(rt):
+    """Without autograd the scores come back as the (B, N) view of a buffer whose rows start on
+    128-byte boundaries.  Everything train.py does with them -- BCELoss, the in-place
+    filter_predictions (gather / masked assignment / scatter_), sort + gather in metrics -- must
+    give what it gives on a dense copy; R_TUCKER_AMD_ROW_ALIGN=1 is the dense layout."""
+    n_ent, n_rel, B, rank = 1001, 5, 40, (3, 24, 24)            # 1001 is not a multiple of 32
+    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 8)
+    h, r = gen.make_queries(n_ent, n_rel, B, 8)
+    p = rt.score_1vN(*dev(core, R, S, O, h, r))
+    assert p.shape == (B, n_ent) and p.stride(1) == 1 and p.stride(0) % 32 == 0 and p.data_ptr() % 128 == 0
+    assert not p.is_contiguous()
+    dense = p.contiguous()
+    rng = np.random.default_rng(8)
+    targets = torch.from_numpy((rng.random((B, n_ent)) < 0.01).astype(np.float32)).cuda()
+    obj = torch.from_numpy(rng.integers(0, n_ent, (B, 1))).cuda()
+    targets.scatter_(1, obj, 1.0)
+    assert torch.equal(torch.nn.BCELoss()(p, targets), torch.nn.BCELoss()(dense, targets))
+    fa, ta = orc.filter_predictions_ref(p, targets.clone(), obj)          # in place, on the padded view
+    fb, tb = orc.filter_predictions_ref(dense, targets.clone(), obj)
+    assert torch.equal(fa, fb) and torch.equal(ta, tb) and fa.data_ptr() == p.data_ptr()
+    ra, _ = orc.ranks_ref(fa, ta)
+    rb, _ = orc.ranks_ref(fb, tb)
+    assert torch.equal(ra, rb)
+
+
 def test_wide_dynamic_range_rows(rt):
     """Per-row power-of-two scaling of the split-fp16 path: rows of O and S spanning
     30 orders of magnitude must not lose accuracy or overflow."""
