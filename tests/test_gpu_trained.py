@@ -1,0 +1,56 @@
+"""MRR parity on TRAINED parameters.  No reference checkpoint exists, so the HIP path
+trains its own: tools/train_adam_wn18rr.py (R_TuckER parameters, torch Adam on bce_loss_1vN --
+forward, loss, backward in HIP kernels) for a minute's worth of epochs; then the WN18RR test split
+is evaluated twice with those parameters: on the device (HIP scores + filtered rank kernel) and by
+the oracle on the CPU (reference op sequence + filter_predictions + sort).  north_star: MRR within
++-0.001."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_trained_model_mrr_parity():
+    assert torch.cuda.is_available()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_adam_wn18rr as tr
+    import r_tucker_amd as rt
+    log = []
+    model, data, test_set = tr.train(epochs=60, lr=5e-3, log=log.append)
+    dev_metrics, _ = rt.evaluate(model, test_set, batch_size=512)
+    assert dev_metrics["mrr"] > 0.15, log                      # the loop did learn to rank
+
+    core, R, S, O = [p.detach().cpu() for p in (model.core, model.R.weight, model.S.weight, model.O.weight)]
+    feats = test_set.features
+    n = len(feats)
+    ranks_cpu = []
+    for lo in range(0, n, 512):
+        ids = np.arange(lo, min(lo + 512, n))
+        f = torch.from_numpy(feats[ids])
+        P = orc.score_ref(core, R, S, O, f[:, 0], f[:, 1])
+        ranks_cpu.append(orc.filter_and_rank_stable(P, test_set.dense_targets(ids), f[:, 2]))
+    ranks_cpu = torch.cat(ranks_cpu).double()
+    mrr_cpu = float((1.0 / ranks_cpu).mean())
+
+    flt = rt.DeviceFilter(test_set, "cuda")
+    T = rt.Tucker(model.core.data, [model.R.weight, model.S.weight, model.O.weight])
+    ranks_dev = []
+    with torch.no_grad():
+        for lo in range(0, n, 512):
+            ids = torch.arange(lo, min(lo + 512, n), device="cuda")
+            f = flt.features[ids]
+            ranks_dev.append(rt.filtered_ranks(model(f[:, 0], f[:, 1])(T), f[:, 2], flt, ids))
+    ranks_dev = torch.cat(ranks_dev).cpu().double()
+    mrr_dev = float((1.0 / ranks_dev).mean())
+    same = float((ranks_dev == ranks_cpu).double().mean())
+    print(f"\ntrained model: MRR device {mrr_dev:.5f}  CPU oracle {mrr_cpu:.5f}  identical ranks {same:.4f}")
+    assert abs(mrr_dev - dev_metrics["mrr"]) < 1e-9
+    assert abs(mrr_dev - mrr_cpu) <= 1e-3
+    assert same >= 0.99
