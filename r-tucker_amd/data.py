@@ -23,18 +23,18 @@ class Data:
     train-relations + unseen valid + unseen test."""
 
     def __init__(self, data_dir="data/FB15k-237/", reverse=False):
-        self.train_data = self.load_data(data_dir, "train.txt", reverse)
-        self.valid_data = self.load_data(data_dir, "valid.txt", reverse)
-        self.test_data = self.load_data(data_dir, "test.txt", reverse)
+        for split in ("train", "valid", "test"):
+            rows = self.load_data(data_dir, split + ".txt", reverse)
+            setattr(self, split + "_data", rows)                       # train_data / valid_data / test_data
+            setattr(self, split + "_relations", self.get_relations(rows))
         self.data = self.train_data + self.valid_data + self.test_data
-        self.train_relations = self.get_relations(self.train_data)
-        self.valid_relations = self.get_relations(self.valid_data)
-        self.test_relations = self.get_relations(self.test_data)
         self.entities = self.get_entities(self.data)
+        # relation ids: the train split's relations first, then those only valid / only test introduce
+        # (a relation new to both valid and test appears twice, as in the reference's list)
         seen = set(self.train_relations)
-        self.relations = (self.train_relations
-                          + [x for x in self.valid_relations if x not in seen]
-                          + [x for x in self.test_relations if x not in seen])
+        self.relations = list(self.train_relations)
+        for extra in (self.valid_relations, self.test_relations):
+            self.relations += [x for x in extra if x not in seen]
 
     @staticmethod
     def load_data(data_dir, file="train.txt", reverse=False):
