@@ -87,7 +87,7 @@ def _stream_ptr(device):
 
 
 def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None, out=None,
-             out_dtype=torch.float32):
+             out_dtype=torch.float32, padded=None):
     lib = _lib.load()
     _require_gpu("core", core)
     if core.dtype not in (torch.float32, torch.bfloat16):
@@ -117,7 +117,9 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
     if out_dtype == torch.bfloat16 and (not bf16 or want_v or not sigmoid or exact):
         raise RuntimeError("bfloat16 scores: bf16 operands, sigmoid=True, no autograd (the reference's bf16 eval path)")
     if out is None:
-        out = torch.empty((B, N), dtype=torch.float32, device=dev) if want_v else alloc_scores(B, N, dev, dtype=out_dtype)
+        # dense when the scores are handed to autograd's caller, 128-byte aligned rows otherwise
+        dense = want_v if padded is None else not padded
+        out = torch.empty((B, N), dtype=torch.float32, device=dev) if dense else alloc_scores(B, N, dev, dtype=out_dtype)
     elif (tuple(out.shape) != (B, N) or out.dtype != out_dtype or out.device != dev or out.stride(1) != 1
           or out.stride(0) < N):
         raise RuntimeError(f"out must be a {out_dtype} ({B}, {N}) tensor on {dev} with unit column stride")
@@ -207,6 +209,7 @@ def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt):
     lib = _lib.load()
     dev = dZ.device
     B, N = dZ.shape
+    ldz = dZ.stride(0) if B > 1 else N      # dZ may be the (B, N) view of a padded buffer (bce_loss_1vN)
     c = O.shape[1]
     with torch.cuda.device(dev):
         sp = _stream_ptr(dev)
@@ -214,13 +217,13 @@ def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt):
         if needs[3]:
             # gO[j, k] = sum_d dZ[d, j] * v[d, k]   -- fp32 MFMA GEMM, both operands M-major
             gO = torch.empty((N, c), dtype=torch.float32, device=dev)
-            _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, N, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
+            _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, ldz, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
                        "rtk_gemm_f32 (dO)")
         # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K with float atomics
         Of = O.contiguous()
         dv = torch.empty((B, c), dtype=torch.float32, device=dev)
         splits = max(1, min(256, N // 512))
-        _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, N, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
+        _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, ldz, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
                                            splits, sp), "rtk_gemm_f32_splitk (dv)")
     Rb, Sb = R[r], S[h]
     W = torch.einsum("abc,dc->dab", core, dv)                            # (B, a, b)
@@ -241,7 +244,8 @@ class _BceLoss1vN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, core, R, S, O, subject_idx, relation_idx, pair_slot, pair_ptr, pair_obj, label_smoothing):
-        P, v = _forward(core, R, S, O, subject_idx, relation_idx, True, False, want_v=True)
+        # the scores never leave this function pair: aligned rows for them too
+        P, v = _forward(core, R, S, O, subject_idx, relation_idx, True, False, want_v=True, padded=True)
         lib = _lib.load()
         dev = P.device
         B, N = P.shape
