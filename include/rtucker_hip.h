@@ -168,6 +168,10 @@ int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda,
 /* Backward of the logistic (R_TuckER.py:48): dZ = dP * P * (1 - P), n contiguous elements. */
 int rtk_sigmoid_grad_f32(const float *dP, const float *P, float *dZ, int64_t n, void *stream);
 
+/* the same with a row pitch (in elements) per array: dZ on 128-byte aligned rows for the GEMMs */
+int rtk_sigmoid_grad_rows_f32(const float *dP, int64_t ld_dp, const float *P, int64_t ld_p, float *dZ,
+                              int64_t ld_dz, int64_t batch, int64_t n, void *stream);
+
 /*
  * Filtered rank of the queried object, on the device -- replaces the full B x N sort of the
  * eval tail (train.py:115-117; src/utils/utils.py:15-22 filter_predictions + src/utils/metrics.py:5-8).

@@ -39,6 +39,7 @@ SIGNATURES = {
     "rtk_gemm_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _u, _p]),
     "rtk_gemm_f32_splitk": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _i, _p]),
     "rtk_sigmoid_grad_f32": (_i, [_p, _p, _p, _i64, _p]),
+    "rtk_sigmoid_grad_rows_f32": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
     "rtk_filtered_rank_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "rtk_bce_rows_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, _p]),
     "rtk_bce_grad_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, C.c_float, _p]),

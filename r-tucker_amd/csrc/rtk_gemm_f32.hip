@@ -291,7 +291,31 @@ __global__ __launch_bounds__(256) void sigmoid_grad_kernel(const float *__restri
     if (blockIdx.x == 0)
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) dZ[i] = dP[i] * P[i] * (1.0f - P[i]);
 }
+// the same, row by row, for arrays with different row pitches (dense dP / P, dZ on aligned rows)
+__global__ __launch_bounds__(256) void sigmoid_grad_rows_kernel(const float *__restrict__ dP, int64_t ld_dp,
+                                                                const float *__restrict__ P, int64_t ld_p,
+                                                                float *__restrict__ dZ, int64_t ld_dz, int n) {
+    const float *g = dP + (int64_t)blockIdx.y * ld_dp, *p = P + (int64_t)blockIdx.y * ld_p;
+    float *z = dZ + (int64_t)blockIdx.y * ld_dz;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const float pj = p[j];
+        z[j] = g[j] * pj * (1.0f - pj);
+    }
+}
 }  // namespace
+
+// dZ = dP * P * (1 - P) with a row pitch per array (elements): lets dZ live on 128-byte aligned rows
+// (the backward GEMMs read it with vector loads) while dP / P are the caller's dense tensors.
+extern "C" int rtk_sigmoid_grad_rows_f32(const float *dP, int64_t ld_dp, const float *P, int64_t ld_p, float *dZ,
+                                         int64_t ld_dz, int64_t batch, int64_t n, void *stream) {
+    RTK_REQUIRE(dP && P && dZ && batch > 0 && n > 0, RTK_ERR_BAD_ARG, "rtk_sigmoid_grad_rows_f32: bad argument");
+    RTK_REQUIRE(ld_dp >= n && ld_p >= n && ld_dz >= n, RTK_ERR_BAD_ARG, "rtk_sigmoid_grad_rows_f32: row pitch < n");
+    RTK_REQUIRE(batch <= 65535 && n < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_sigmoid_grad_rows_f32: dimension too large");
+    const unsigned gx = (unsigned)(rtk_cdiv(n, 256 * 8) < 1 ? 1 : (rtk_cdiv(n, 256 * 8) > 32 ? 32 : rtk_cdiv(n, 256 * 8)));
+    hipLaunchKernelGGL(sigmoid_grad_rows_kernel, dim3(gx, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, dP, ld_dp, P,
+                       ld_p, dZ, ld_dz, (int)n);
+    return rtk_check_launch("rtk_sigmoid_grad_rows_f32");
+}
 
 // dZ = dP * P * (1 - P): the logistic's derivative applied to the incoming gradient (backward of
 // R_TuckER.py:48).  All three arrays are contiguous with n elements; dZ may alias dP.

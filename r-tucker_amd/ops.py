@@ -194,10 +194,15 @@ class _Score1vN(torch.autograd.Function):
         grad_out = grad_out.contiguous().float()
         with torch.cuda.device(dev):
             sp = _stream_ptr(dev)
-            if ctx.sigmoid:      # dZ = dP * P * (1 - P)   (HIP)
+            if ctx.sigmoid and B > 65535:   # (the row-pitch kernel's grid limit) dense dZ
                 dZ = torch.empty_like(out)
                 _lib.check(lib.rtk_sigmoid_grad_f32(grad_out.data_ptr(), out.data_ptr(), dZ.data_ptr(), out.numel(), sp),
                            "rtk_sigmoid_grad_f32")
+            elif ctx.sigmoid:    # dZ = dP * P * (1 - P)   (HIP), written on 128-byte aligned rows for the GEMMs
+                dZ = alloc_scores(B, N, dev)
+                _lib.check(lib.rtk_sigmoid_grad_rows_f32(grad_out.data_ptr(), N, out.data_ptr(), out.stride(0) if B > 1 else N,
+                                                         dZ.data_ptr(), dZ.stride(0) if B > 1 else N, B, N, sp),
+                           "rtk_sigmoid_grad_rows_f32")
             else:
                 dZ = grad_out
         return _grads_from_dZ(core, R, S, O, h, r, v, dZ, ctx.needs_input_grad, pdt) + (None,) * 5
