@@ -188,6 +188,30 @@ def test_padded_row_pitch_is_transparent_to_the_callers_ops(rt):
     assert torch.equal(ra, rb)
 
 
+def test_calls_are_graph_capturable(rt):
+    """The ABI only enqueues on the given stream (no allocation, no synchronisation): a captured
+    HIP graph of the whole scoring call replays with fresh ids and gives the eager result."""
+    n_ent, n_rel, B, rank = 4099, 9, 96, (5, 64, 64)
+    core, R, S, O = dev(*gen.make_params(n_ent, n_rel, rank, 12))
+    q1, q2 = dev(*gen.make_queries(n_ent, n_rel, B, 1)), dev(*gen.make_queries(n_ent, n_rel, B, 2))
+    out = rt.ops.alloc_scores(B, n_ent, "cuda")
+    hs, rs = q1[0].clone(), q1[1].clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            rt.score_1vN_into(core, R, S, O, hs, rs, out)      # first use outside the capture (function attributes, workspace)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rt.score_1vN_into(core, R, S, O, hs, rs, out)
+    for q in (q1, q2):
+        hs.copy_(q[0])
+        rs.copy_(q[1])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, rt.score_1vN(core, R, S, O, q[0], q[1]))
+
+
 def test_wide_dynamic_range_rows(rt):
     """Per-row power-of-two scaling of the split-fp16 path: rows of O and S spanning
     30 orders of magnitude must not lose accuracy or overflow."""
