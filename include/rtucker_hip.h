@@ -190,6 +190,13 @@ int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t 
                           int32_t *ranks_out, double *bce_rows_out, void *stream);
 
 /*
+ * Batch sums of the metrics (src/utils/metrics.py:4-22: mrr = sum 1/rank, hits@k = #(rank <= k)) and of
+ * the BCE row sums, ADDED to acc5[0..4] = (sum 1/rank, hits@1, hits@3, hits@10, bce) -- the running
+ * totals train.py:118-121 keeps per evaluation, without a device -> host copy per batch.
+ */
+int rtk_rank_metrics_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double *acc5, void *stream);
+
+/*
  * The same ranking with the entity dimension sharded over GPUs (no gather of the scores): a rank
  * holds columns [col0, col0 + n_local) of the score matrix; the count is a sum over columns.
  *   1. rtk_target_scores_f32: pt_out[d] = P[d, obj_idx[d] - col0] where this rank owns the queried

@@ -43,6 +43,7 @@ SIGNATURES = {
     "rtk_filtered_rank_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "rtk_bce_rows_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, _p]),
     "rtk_bce_grad_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, C.c_float, _p]),
+    "rtk_rank_metrics_f64": (_i, [_p, _p, _i64, _p, _p]),
     "rtk_target_scores_f32": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p]),
     "rtk_filtered_rank_partial_f32": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
 }

@@ -102,7 +102,40 @@ __global__ __launch_bounds__(256) void target_scores_kernel(const float *__restr
     pt_out[d] = (j >= 0 && j < N) ? P[(int64_t)d * ld + j] : -INFINITY;
 }
 
+// acc[0] += sum 1/rank, acc[1..3] += #(rank <= 1 / 3 / 10), acc[4] += sum of the BCE row sums
+// (src/utils/metrics.py:4-22 returns exactly these batch sums; train.py:118-121 adds them up)
+__global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__restrict__ ranks,
+                                                           const double *__restrict__ bce_rows, int B,
+                                                           double *__restrict__ acc) {
+    __shared__ double s[4][5];
+    const int t = threadIdx.x;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int d = t; d < B; d += 256) {
+        const int rk = ranks[d];
+        v[0] += 1.0 / (double)rk;
+        v[1] += rk <= 1;
+        v[2] += rk <= 3;
+        v[3] += rk <= 10;
+        if (bce_rows) v[4] += bce_rows[d];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        if ((t & 63) == 0) s[t >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (t < 5) acc[t] += s[0][t] + s[1][t] + s[2][t] + s[3][t];   // one workgroup, launches are stream-ordered: no atomics needed
+}
+
 }  // namespace
+
+extern "C" int rtk_rank_metrics_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double *acc5,
+                                    void *stream) {
+    RTK_REQUIRE(ranks && acc5 && batch > 0 && batch < (1ll << 31), RTK_ERR_BAD_ARG, "rtk_rank_metrics_f64: bad argument");
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ranks, bce_rows, (int)batch, acc5);
+    return rtk_check_launch("rtk_rank_metrics_f64");
+}
 
 extern "C" int rtk_target_scores_f32(const float *P, int64_t batch, int64_t n_local, int64_t ld, int64_t col0,
                                      const int64_t *obj_idx, float *pt_out, void *stream) {

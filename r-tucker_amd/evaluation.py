@@ -130,21 +130,22 @@ def evaluate(model, dataset, batch_size=512, device=None, flt: DeviceFilter = No
     else:
         T = Tucker(model.core.data, [model.R.weight, model.S.weight, model.O.weight])
     n = len(dataset)
-    sums = {"mrr": 0.0, "hits@1": 0.0, "hits@3": 0.0, "hits@10": 0.0}
-    loss_sum, n_batches = 0.0, 0
-    acc = None
+    lib = _lib.load()
+    acc = torch.zeros(5, dtype=torch.float64, device=device)   # running sums on the device: one sync at the end
+    loss_terms = 0
+    n_batches = 0
     for lo in range(0, n, batch_size):
-        ids = torch.arange(lo, min(lo + batch_size, n), device=device)
-        f = flt.features[ids]
+        hi = min(lo + batch_size, n)
+        ids = torch.arange(lo, hi, device=device)
+        f = flt.features[lo:hi]
         P = model(f[:, 0], f[:, 1])(T)
         ranks, bce = filtered_ranks(P, f[:, 2], flt, ids, want_bce=True)
-        m = metrics_from_ranks(ranks)
-        vec = torch.stack([m["mrr"], m["hits@1"].double(), m["hits@3"].double(), m["hits@10"].double(),
-                           bce.sum() / (P.shape[0] * P.shape[1])])
-        acc = vec if acc is None else acc + vec          # stays on the device: one sync at the end
+        # the reference averages the per-batch MEAN losses (train.py:113,125): scale this batch's row sums
+        bce.mul_(1.0 / (P.shape[0] * P.shape[1]))
+        with torch.cuda.device(device):
+            _lib.check(lib.rtk_rank_metrics_f64(ranks.data_ptr(), bce.data_ptr(), hi - lo, acc.data_ptr(),
+                                                torch.cuda.current_stream(device).cuda_stream), "rtk_rank_metrics_f64")
         n_batches += 1
-    acc = acc.cpu()
-    for k, v in zip(("mrr", "hits@1", "hits@3", "hits@10"), acc[:4].tolist()):
-        sums[k] = v / n
-    loss_sum = acc[4].item()
-    return sums, loss_sum / n_batches
+    acc = acc.cpu().tolist()
+    sums = {"mrr": acc[0] / n, "hits@1": acc[1] / n, "hits@3": acc[2] / n, "hits@10": acc[3] / n}
+    return sums, acc[4] / n_batches
