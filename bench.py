@@ -9,7 +9,15 @@ over one batch of synthetic (h, r) queries, operands already resident in HBM.
 N = 1 workload: BASELINE.json configs[1] -- WN18RR asymmetric rank (10,200,200),
 batch 512, fp32, 40 943 entities, 22 relations.  N > 1: the entity matrix O is
 row-sharded over the ranks and the per-shard score blocks are all-gathered with RCCL
-(north_star); every rank scores the same batch against its shard.
+(north_star); every rank scores the same batch against its shard ("strong" scaling).
+For a large relation rank (a > 32) stage 1 is split over the ranks too (each contracts
+ceil(B/N) queries, one all-gather of the B x c vectors).
+
+Parameters are fixed while a split is evaluated (train.py:94-125 scores every batch of valid /
+test with the same extract_tensor(model)), so by default the relation tables G x_0 R[r] -- a
+function of the parameters only -- are built once per EVAL_BATCHES steps inside the timed
+region (`--tables cached`, an evaluation pass of that many batches) and every step runs the
+subject-mode contraction + the score kernel; `--tables per-batch` rebuilds them in every step.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline`
 for the dominant kernel (the score kernel, timed with HIP events on its own stream
@@ -20,7 +28,6 @@ from __future__ import annotations
 
 import argparse
 import datetime
-import ctypes as C
 import json
 import os
 import sys
@@ -31,22 +38,23 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-
-import gen  # noqa: E402
 
 WORKLOADS = {
-    # name: (n_ent, n_rel, batch, rank, dtype)
-    "wn18rr_asym_r10x200_b512_f32": (40943, 22, 512, (10, 200, 200), "f32"),
-    # BASELINE.json configs[2] (parity-test case, selectable for measurements; not the default bench line)
-    "fb15k237_sym_r200x200_b2048_bf16": (14541, 474, 2048, (200, 200, 200), "bf16"),
-    # one GPU's share of BASELINE.json configs[4] (1 M entities over 8 GPUs): shard-local measurement
+    # name: (n_ent, n_rel, batch, rank, dtype); the entity matrix is row-sharded over the ranks of the run
+    "wn18rr_asym_r10x200_b512_f32": (40943, 22, 512, (10, 200, 200), "f32"),          # BASELINE configs[1]: the bench line
+    # parity-test / measurement cases (selectable; not the default line)
+    "fb15k237_sym_r200x200_b2048_bf16": (14541, 474, 2048, (200, 200, 200), "bf16"),  # configs[2]
+    "fb15k_asym_r200x200_b512_f32": (14951, 2690, 512, (200, 200, 200), "f32"),       # configs[3], B = 512
+    "fb15k_asym_r200x200_b2048_f32": (14951, 2690, 2048, (200, 200, 200), "f32"),     # configs[3], B = 2048
+    "synthetic1m_r256x512_b8192_bf16": (1_000_000, 1000, 8192, (256, 512, 512), "bf16"),  # configs[4]: 1 M entities / world
+    # one GPU's share of configs[4] (1 M entities over 8 GPUs): shard-local measurement on a single GPU
     "synthetic1m_shard125k_r256x512_b8192_bf16": (125000, 1000, 8192, (256, 512, 512), "bf16"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+EVAL_BATCHES = 16      # --tables cached: the relation tables are rebuilt every this many steps (one "evaluation pass")
 
 
-def cpu_baseline(n_ent, n_rel, B, rank, pool, budget_s=15.0):
+def cpu_baseline(gen, n_ent, n_rel, B, rank, pool, budget_s=15.0):
     """The oracle (CPU restatement of the reference's five torch ops) on the host cores.
     torch's intra-op thread count is swept (the box exposes more hardware threads than the
     cgroup grants; oversubscription makes the small GEMMs slower) and the best is reported."""
@@ -87,7 +95,11 @@ def main():
     ap.add_argument("--exact", action="store_true", help="exact-fp32 MFMA score kernel instead of split-fp16")
     ap.add_argument("--sigmoid", default=None, choices=["fast", "exact"], help="logistic of the fused epilogue (default: package default)")
     ap.add_argument("--out-dtype", choices=["f32", "bf16"], default="f32",
-                    help="bf16 workloads: dtype of the score matrix (bf16 = what the reference's bf16 model returns)")
+                    help="bf16 workloads: dtype of the score matrix (bf16 = what the reference's bf16 model returns; halves the exchange)")
+    ap.add_argument("--tables", choices=["cached", "per-batch"], default="cached",
+                    help="relation tables: built once per evaluation pass of %d batches (default) or in every step" % EVAL_BATCHES)
+    ap.add_argument("--stage1", choices=["auto", "replicated", "split"], default="auto",
+                    help="multi-GPU: query vectors computed by every rank, or batch-split + all-gather (auto: split for relation rank > 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="multi-GPU: run the all-gather of step i before step i+1 starts (default: it overlaps the next step's kernels)")
@@ -107,8 +119,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=3))
 
-    import r_tucker_amd as rt
-    from r_tucker_amd import _lib
+    import r_tucker_amd as rt  # noqa: F401
+    from r_tucker_amd import _lib, synthetic as gen
     lib = _lib.load()
     from r_tucker_amd import ops as _ops
     sig_mode = args.sigmoid or _ops.DEFAULT_SIGMOID
@@ -117,6 +129,10 @@ def main():
     n_ent, n_rel, B, trank, dtype = WORKLOADS[args.workload]
     a, b, c = trank
     sym = "_sym_" in args.workload
+    bf16 = dtype == "bf16"
+    n_loc = -(-n_ent // world)
+    lo = min(rank * n_loc, n_ent)
+    hi = min(lo + n_loc, n_ent)
     if n_ent * trank[1] > 50_000_000:      # big synthetic shapes: generate on the device
         gd = torch.Generator(device=dev).manual_seed(322)
         core = torch.randn(trank, generator=gd, device=dev) * (3.0 / float(np.sqrt(a * b * c)))
@@ -125,26 +141,31 @@ def main():
         O = S if sym else torch.randn((n_ent, c), generator=gd, device=dev)
     else:
         core, R, S, O = [torch.from_numpy(x).to(dev) for x in gen.make_params(n_ent, n_rel, trank, 322, shared=sym)]
-    bf16 = dtype == "bf16"
     if bf16:
-        core, R, S, O = [x.to(torch.bfloat16) for x in (core, R, S, O)]
+        core, R, S = [x.to(torch.bfloat16) for x in (core, R, S)]
+        O = S if sym else O.to(torch.bfloat16)
     dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
     esz = 2 if bf16 else 4
     pool_cpu = [tuple(torch.from_numpy(x) for x in gen.make_queries(n_ent, n_rel, B, 1000 + i)) for i in range(64)]
     pool = [(h.to(dev), r.to(dev)) for h, r in pool_cpu]
 
-    # entity shard of this rank (row block of O); N = 1: the whole matrix
-    n_loc = -(-n_ent // world)
-    lo = min(rank * n_loc, n_ent)
-    hi = min(lo + n_loc, n_ent)
-    O_loc = torch.zeros((n_loc, c), dtype=O.dtype, device=dev)
-    O_loc[: hi - lo] = O[lo:hi]                       # last shard zero-padded to equal size
-    # rank p's (B, n_loc) block is slot p of the gather buffer: the kernel writes its block in place
-    # row pitch of the score block: rows start on 128-byte boundaries (r_tucker_amd.ops.ROW_ALIGN,
-    # the layout score_1vN allocates; R_TUCKER_AMD_ROW_ALIGN=1 gives the dense (B, n_loc) layout)
+    # entity shard of this rank (row block of O); N = 1: the whole matrix.  The subject-lookup matrix S
+    # stays replicated.
+    if world == 1:
+        O_loc = O
+    else:
+        O_loc = torch.zeros((n_loc, c), dtype=O.dtype, device=dev)
+        O_loc[: hi - lo] = O[lo:hi]                   # last shard zero-padded to equal size
+        if not sym:
+            del O
+    # rank p's (B, n_loc) block is slot p of the gather buffer: the kernel writes its block in place;
+    # rows start on 128-byte boundaries (r_tucker_amd.ops.ROW_ALIGN, the layout score_1vN allocates;
+    # R_TUCKER_AMD_ROW_ALIGN=1 gives the dense (B, n_loc) layout)
     obf = args.out_dtype == "bf16"
     if obf and (not bf16 or args.exact or sig_mode != "fast"):
         raise SystemExit("--out-dtype bf16 needs a bf16 workload and the fast logistic")
+    if bf16 and args.exact:
+        raise SystemExit("--exact is an fp32 kernel")
     osz = 2 if obf else 4
     ra = _ops.ROW_ALIGN * (4 // osz) if _ops.ROW_ALIGN > 1 else 1
     pitch = -(-n_loc // ra) * ra
@@ -159,13 +180,69 @@ def main():
 
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
-    ws = torch.zeros(lib.rtk_workspace_bytes(dcode, B, n_rel, a, b, c), dtype=torch.uint8, device=dev)
+    cached = args.tables == "cached"
+    split1 = world > 1 and (args.stage1 == "split" or (args.stage1 == "auto" and a > 32))
+    ws_bytes = max(lib.rtk_workspace_bytes(dcode, B, n_rel, a, b, c), lib.rtk_from_tables_workspace_bytes(B, n_rel))
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
     qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev)
     qv_fn = lib.rtk_query_vectors_bf16 if bf16 else lib.rtk_query_vectors_f32
+    ft_fn = lib.rtk_query_vectors_from_tables_bf16 if bf16 else lib.rtk_query_vectors_from_tables_f32
+    tb_fn = lib.rtk_relation_tables_bf16 if bf16 else lib.rtk_relation_tables_f32
     sp_fn = lib.rtk_score_packed_bf16 if bf16 else lib.rtk_score_packed_f32
-    if bf16 and args.exact:
-        raise SystemExit("--exact is an fp32 kernel")
-    v = torch.empty((B, c), dtype=torch.float32, device=dev)
+    need_v = args.exact or split1
+    v = torch.empty((B, c), dtype=torch.float32, device=dev) if need_v else None
+    tables = tws = None
+    if cached:
+        tables = torch.empty((n_rel, b, c), dtype=torch.float32, device=dev)
+        tws = torch.zeros(max(256, lib.rtk_relation_tables_workspace_bytes(dcode, n_rel, a, b, c)), dtype=torch.uint8, device=dev)
+    # stage 1 split over the ranks: this rank's slice of the batch, the gathered (B_loc * world, c) vectors
+    B_loc = -(-B // world)
+    qlo, qhi = min(rank * B_loc, B), min((rank + 1) * B_loc, B)
+    v_all = torch.zeros((world * B_loc, c), dtype=torch.float32, device=dev) if split1 else None
+
+    def stage1(h, r):
+        """query vectors of the batch -> packed planes in qp (and/or fp32 v)"""
+        if split1:
+            nq = qhi - qlo
+            mine = v_all[rank * B_loc:(rank + 1) * B_loc]
+            if nq > 0:
+                hp, rp = h.data_ptr() + 8 * qlo, r.data_ptr() + 8 * qlo
+                if cached:
+                    _lib.check(ft_fn(tables.data_ptr(), n_rel, b, c, S.data_ptr(), n_ent, rp, hp, nq, mine.data_ptr(), None,
+                                     ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_from_tables")
+                else:
+                    _lib.check(qv_fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent, rp, hp, nq,
+                                     mine.data_ptr(), None, ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors")
+            dist.all_gather_into_tensor(v_all.view(-1), mine.reshape(-1))
+            if not args.exact:
+                _lib.check(lib.rtk_pack_query_vectors(v_all.data_ptr(), B, c, dcode, qp.data_ptr(), sp), "rtk_pack_query_vectors")
+            return v_all
+        vo = v.data_ptr() if args.exact else None
+        qo = None if args.exact else qp.data_ptr()
+        if cached:
+            _lib.check(ft_fn(tables.data_ptr(), n_rel, b, c, S.data_ptr(), n_ent, r.data_ptr(), h.data_ptr(), B, vo, qo,
+                             ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_from_tables")
+        else:
+            _lib.check(qv_fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent, r.data_ptr(), h.data_ptr(), B,
+                             vo, qo, ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors")
+        return v
+
+    def step_local(i, ev=None, out=out):
+        h, r = pool[i % len(pool)]
+        if cached and i % EVAL_BATCHES == 0:     # a new "evaluation pass": the parameters may have changed
+            _lib.check(tb_fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, tables.data_ptr(), tws.data_ptr(), tws.numel(), sp),
+                       "rtk_relation_tables")
+        vv = stage1(h, r)
+        if ev:
+            ev[0].record(stream)
+        if args.exact:
+            _lib.check(lib.rtk_score_f32(vv.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch,
+                                         _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
+        else:
+            _lib.check(sp_fn(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch, sflags, sp),
+                       "rtk_score_packed")
+        if ev:
+            ev[1].record(stream)
 
     def step(i, ev=None):
         k = i % n_buf
@@ -187,23 +264,6 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
-    def step_local(i, ev=None, out=out):
-        h, r = pool[i % len(pool)]
-        _lib.check(qv_fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent,
-                                             r.data_ptr(), h.data_ptr(), B, v.data_ptr() if args.exact else None,
-                                             None if args.exact else qp.data_ptr(), ws.data_ptr(), ws.numel(), sp),
-                   "rtk_query_vectors_f32")
-        if ev:
-            ev[0].record(stream)
-        if args.exact:
-            _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch,
-                                         _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
-        else:
-            _lib.check(sp_fn(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch,
-                                                sflags, sp), "rtk_score_packed_f32")
-        if ev:
-            ev[1].record(stream)
-
     def barrier():
         drain()
         if use_dist:
@@ -214,7 +274,7 @@ def main():
         step(i)
     # HIP events bracket the score kernel on its stream on every 8th timed step (an event pair
     # costs a few us of stream time; sampling keeps the timed region representative)
-    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) if i % 8 == 0 else None
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) if i % 8 == 0 else None
               for i in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -226,6 +286,10 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # out-of-range ids are flagged by the kernels (sticky word in the workspace); synthetic ids never are
+    flag = torch.zeros(1, dtype=torch.int32)
+    flag.copy_(ws[:4].view(torch.int32))
+    assert int(flag) & 1 == 0, "device error word set"
 
     events = [e for e in events if e is not None]
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
@@ -242,14 +306,18 @@ def main():
     # read the query vectors once (SURVEY.md 8d formula restricted to this kernel)
     alg_bytes = n_loc * c * esz + B * n_loc * osz + B * c * esz
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if they match
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tj = json.load(f)
-        if tj["workload"] == args.workload and world == 1 and not args.exact:
-            traffic = tj["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM bytes per launch: NOT measured by this run -- taken from the committed rocprofv3 PMC passes
+    # (profiles/*_traffic.json, collected by tools/profile_round.sh) when they are for this workload
+    traffic = traffic_source = None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tj = json.load(f)
+            if tj["workload"] == args.workload and world == 1 and not args.exact:
+                traffic, traffic_source = tj["traffic_bytes"], "profiles/" + name
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     result = {
         "metric": "1-vs-N triples scored/sec", "value": args.steps * B / dt, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -258,15 +326,18 @@ def main():
                    "batch": B, "scores_per_query": n_ent, "score_row_pitch": pitch, "score_dtype": args.out_dtype,
                    "score_kernel": "exact_f32_mfma" if args.exact else ("bf16_mfma" if bf16 else "split_fp16_mfma"),
                    "sigmoid": "exact" if args.exact else sig_mode,
+                   "relation_tables": (f"cached: rebuilt every {EVAL_BATCHES} steps inside the timed region" if cached
+                                       else "rebuilt in every step"),
+                   "stage1": "batch split over ranks + all-gather of the query vectors" if split1 else "on every rank",
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
         "scores_per_s": args.steps * B * n_ent / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ("score_bf16_kernel" if bf16 else "score_ws_kernel") if not args.exact else "gemm_f32_kernel",
                      "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
     }
     if use_dist:
-        # the exchange step: every rank receives (P-1) blocks of B*n_loc fp32 over xGMI
+        # the exchange step: every rank receives (P-1) blocks of B*n_loc scores over xGMI
         # (7 links x ~153 GB/s per GPU, MI355X guide); reported next to the shard-local rate
         recv = (world - 1) * B * pitch * osz
         result["exchange"] = {"collective": "all_gather_into_tensor (RCCL, in place)", "ms": gather_ms,
@@ -278,6 +349,8 @@ def main():
         # The same scores consumed shard-locally: filtered rank of a queried object per
         # query with NO gather -- two all-reduces of B words instead of (P-1)*B*n_loc*4 bytes.
         try:
+            if obf:
+                raise RuntimeError("the ranking kernels read fp32 scores (run without --out-dtype bf16)")
             from r_tucker_amd.evaluation import rank_counts_block, target_scores_block
             n_valid = max(0, hi - lo)
             objs = [torch.randint(0, n_ent, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(7 + i))
@@ -297,11 +370,12 @@ def main():
                 dist.all_reduce(counts, op=dist.ReduceOp.SUM)
                 return counts
 
-            for i in range(args.warmup):
+            nr = max(1, min(args.steps, 200))
+            for i in range(min(args.warmup, 20)):
                 step_ranked(i)
             barrier()
             t1 = time.perf_counter()
-            for i in range(args.steps):
+            for i in range(nr):
                 step_ranked(args.warmup + i)
             barrier()
             dtr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
@@ -310,12 +384,12 @@ def main():
             result["ranked_without_gather"] = {
                 "what": "stage 1 + shard-local scores + filtered rank counts; all-reduce(MAX) of B floats and "
                         "all-reduce(SUM) of B int32 per step, no score exchange",
-                "queries_per_s": args.steps * B / dtr, "ms_per_step": dtr / args.steps * 1e3,
+                "queries_per_s": nr * B / dtr, "ms_per_step": dtr / nr * 1e3, "steps": nr,
                 "collective_bytes_per_step": 8 * B}
         except Exception as e:       # the headline line above must survive a failure of this extra leg
             result["ranked_without_gather"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not bf16:
-        result["cpu_baseline"] = cpu_baseline(n_ent, n_rel, B, trank, pool_cpu)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not bf16 and not args.force_dist:
+        result["cpu_baseline"] = cpu_baseline(gen, n_ent, n_rel, B, trank, pool_cpu)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

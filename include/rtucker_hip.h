@@ -92,6 +92,51 @@ int rtk_query_vectors_f32(const float *core, int a, int b, int c,
 size_t rtk_packed_query_bytes(int dtype, int64_t batch, int c);
 
 /*
+ * Packed query planes from fp32 query vectors computed elsewhere (entity-sharded scoring with stage 1
+ * split over the ranks: each rank contracts a slice of the batch, the (batch x c) vectors are
+ * all-gathered, every rank packs them and scores its entity shard with rtk_score_packed_*).  Same
+ * arithmetic as the packing inside rtk_query_vectors_* (bit-identical planes).  dtype: rtk_dtype of
+ * the score kernel that will consume them.
+ */
+int rtk_pack_query_vectors(const float *v, int64_t batch, int c, int dtype, void *q_packed, void *stream);
+
+/*
+ * Stage 1 split at the relation tables, for callers whose parameters stay fixed over many batches
+ * (the evaluation loop, train.py:107-121: extract_tensor(model) is the same tensor for every batch).
+ * The einsum of asymmetric/R_TuckER.py:45 applied to ALL relation rows,
+ *     tables[u, :, :] = sum_a R[u, a] * G[a, :, :]          (n_rel x b x c, fp32)
+ * depends on the parameters only:
+ *   rtk_relation_tables_{f32,bf16}            build it once per parameter version
+ *                                             (bytes: rtk_relation_tables_bytes; scratch:
+ *                                             rtk_relation_tables_workspace_bytes, >= 256)
+ *   rtk_query_vectors_from_tables_{f32,bf16}  per batch: v_d = S[h_d] . tables[r_d]   (R_TuckER.py:43-46
+ *                                             given the tables); same outputs as rtk_query_vectors_*;
+ *                                             workspace rtk_from_tables_workspace_bytes, whose first
+ *                                             word is the sticky error word like the main workspace's.
+ * Same summation order as rtk_query_vectors_*: the results are bit-identical to the uncached path.
+ * `tables` must be 256-byte aligned.
+ */
+size_t rtk_relation_tables_bytes(int64_t n_rel, int b, int c);
+size_t rtk_relation_tables_workspace_bytes(int dtype, int64_t n_rel, int a, int b, int c);
+size_t rtk_from_tables_workspace_bytes(int64_t batch, int64_t n_rel);
+
+int rtk_relation_tables_f32(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
+                            float *tables, void *workspace, size_t workspace_bytes, void *stream);
+int rtk_relation_tables_bf16(const void *core, int a, int b, int c, const void *R, int64_t n_rel,
+                             float *tables, void *workspace, size_t workspace_bytes, void *stream);
+
+int rtk_query_vectors_from_tables_f32(const float *tables, int64_t n_rel, int b, int c,
+                                      const float *S, int64_t n_sub,
+                                      const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                                      float *v_out, void *q_packed,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+int rtk_query_vectors_from_tables_bf16(const float *tables, int64_t n_rel, int b, int c,
+                                       const void *S, int64_t n_sub,
+                                       const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                                       float *v_out, void *q_packed,
+                                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Stage 2: scores  out[d, j] = sigmoid( v[d,:] . O[j,:] )   for j < n_local
  * replaces asymmetric/R_TuckER.py:47-48 ( @ T.factors[2].T ; sigmoid ) and
  * symmetric/R_TuckER.py:44-45.  `O` is the (shard of the) entity matrix,
@@ -158,12 +203,34 @@ int rtk_gemm_f32(const float *A, int a_kmajor, int64_t lda,
                  unsigned flags, void *stream);
 
 /* Split-K variant for short-and-wide products (K >> M, N), e.g. the backward product
- * dv = dZ . O (K = number of entities): C (contiguous, ldc == N) is zeroed and the K chunks are
- * combined with float atomics. */
+ * dv = dZ . O (K = number of entities; autograd of asymmetric/R_TuckER.py:47): the K chunks are
+ * computed by separate workgroups into slabs of the caller's workspace
+ * (rtk_gemm_f32_splitk_workspace_bytes) and added in chunk order by a second kernel -- a fixed
+ * summation order, bit-identical from run to run (no float atomics).  C contiguous (ldc == N). */
+size_t rtk_gemm_f32_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
 int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda,
                         const float *B, int b_kmajor, int64_t ldb,
                         float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                        int splits, void *stream);
+                        int splits, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Backward of stage 1 (autograd of asymmetric/R_TuckER.py:43-46, which the Riemannian gradient
+ * differentiates through loss_fn, train.py:79-82): given dv = d loss / d v (batch x c, fp32),
+ *   g_core (a,b,c) = sum_d R[r_d] (x) S[h_d] (x) dv[d]
+ *   g_R (n_rel,a)  : row u = sum over the queries with r_d = u of  (G x_1 S[h_d] x_2 dv[d])
+ *   g_S (n_sub,b)  : row j = sum over the queries with h_d = j of  (G x_0 R[r_d] x_2 dv[d])
+ * Each output may be NULL (skipped); the others are written in full (untouched rows = 0).
+ * Deterministic: fixed summation order everywhere (the row scatter adds the queries of an id in
+ * increasing query order; no float atomics).  Ranks up to 1024.  Workspace:
+ * rtk_query_bwd_workspace_bytes (2 * batch * a * b floats + the per-query rows).
+ */
+size_t rtk_query_bwd_workspace_bytes(int64_t batch, int a, int b, int c);
+int rtk_query_vectors_bwd_f32(const float *core, int a, int b, int c,
+                              const float *R, int64_t n_rel,
+                              const float *S, int64_t n_sub,
+                              const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                              const float *dv, float *g_core, float *g_R, float *g_S,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the logistic (R_TuckER.py:48): dZ = dP * P * (1 - P), n contiguous elements. */
 int rtk_sigmoid_grad_f32(const float *dP, const float *P, float *dZ, int64_t n, void *stream);

@@ -7,7 +7,8 @@ Nothing here falls back to CPU or to the oracle: without the HIP library, or wit
 non-GPU tensors, the scoring calls raise.
 """
 from .tucker import Tucker, SFTucker  # noqa: F401
-from .ops import score_1vN, score_1vN_into, query_vectors, check_device_errors, bce_loss_1vN  # noqa: F401
+from .ops import (score_1vN, score_1vN_into, query_vectors, check_device_errors, bce_loss_1vN,  # noqa: F401
+                  relation_tables, index_check, pack_query_vectors, score_packed_into)
 from .sharded import EntityShards, ShardedEntityScorer  # noqa: F401
 from . import _lib  # noqa: F401
 from .evaluation import DeviceFilter, evaluate, filtered_ranks, metrics_from_ranks  # noqa: F401

@@ -37,7 +37,18 @@ SIGNATURES = {
     "rtk_score_packed_bf16": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _u, _p]),
     "rtk_score_1vN_bf16": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _u, _p, _sz, _p]),
     "rtk_gemm_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _u, _p]),
-    "rtk_gemm_f32_splitk": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _i, _p]),
+    "rtk_gemm_f32_splitk_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "rtk_gemm_f32_splitk": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _i, _p, _sz, _p]),
+    "rtk_query_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
+    "rtk_query_vectors_bwd_f32": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "rtk_pack_query_vectors": (_i, [_p, _i64, _i, _i, _p, _p]),
+    "rtk_relation_tables_bytes": (_sz, [_i64, _i, _i]),
+    "rtk_relation_tables_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i]),
+    "rtk_from_tables_workspace_bytes": (_sz, [_i64, _i64]),
+    "rtk_relation_tables_f32": (_i, [_p, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
+    "rtk_relation_tables_bf16": (_i, [_p, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
+    "rtk_query_vectors_from_tables_f32": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "rtk_query_vectors_from_tables_bf16": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     "rtk_sigmoid_grad_f32": (_i, [_p, _p, _p, _i64, _p]),
     "rtk_sigmoid_grad_rows_f32": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
     "rtk_filtered_rank_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),

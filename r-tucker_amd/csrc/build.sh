@@ -5,11 +5,14 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-function"
+SRCS="rtk_abi rtk_gemm_f32 rtk_query rtk_query_bwd rtk_score_split rtk_score_ws rtk_score_bf16 rtk_rank rtk_bce"
 pids=()
-for f in rtk_abi rtk_gemm_f32 rtk_query rtk_score_split rtk_score_ws rtk_score_ws2 rtk_score_bf16 rtk_rank rtk_bce; do
+objs=()
+for f in $SRCS; do
   ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
   pids+=($!)
+  objs+=(obj/$f.o)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librtucker_hip.so" obj/*.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librtucker_hip.so" "${objs[@]}"
 echo "built $OUT/librtucker_hip.so"

@@ -59,7 +59,139 @@ static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, i
     return w;
 }
 
-extern "C" int rtk_version(void) { return 100; }
+// ---- cached relation tables (rtk_relation_tables_* / rtk_query_vectors_from_tables_*) ----------
+int rtk_relation_tables_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel, float *tables,
+                                 hipStream_t st);
+int rtk_relation_tables_bf16_impl(const void *core, int a, int b, int c, const void *R, int64_t n_rel, float *tables,
+                                  void *core_t, void *r_packed, hipStream_t st);
+int rtk_from_tables_f32_impl(const float *tables, int64_t n_rel, int b, int c, const float *S, int64_t n_sub,
+                             const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
+                             void *q_packed, const RtkWorkspace &ws, hipStream_t st);
+int rtk_from_tables_bf16_impl(const float *tables, int64_t n_rel, int b, int c, const void *S, int64_t n_sub,
+                              const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
+                              void *q_packed, const RtkWorkspace &ws, hipStream_t st);
+
+// scratch of the tables build: only the bf16 large-relation-rank path needs any (transposed core, packed R rows)
+struct TablesWs {
+    void *core_t, *r_packed;
+    size_t total;
+};
+static TablesWs carve_tables(void *base, int dtype, int64_t n_rel, int a, int b, int c) {
+    TablesWs w;
+    unsigned char *p = (unsigned char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *q = p ? p + off : nullptr;
+        off += rtk_align_up(bytes, 256);
+        return q;
+    };
+    (void)take(256);
+    const bool big_a = dtype == RTK_BF16 && a > 32 && a <= 512;
+    w.core_t = big_a ? take((size_t)a * b * c * 2) : nullptr;
+    w.r_packed = big_a ? take(packed_bytes(RTK_BF16, n_rel, a)) : nullptr;
+    w.total = off;
+    return w;
+}
+
+// workspace of rtk_query_vectors_from_tables_*: header + the slot order of the queries (slots = relation ids)
+static RtkWorkspace carve_ft(void *base, int64_t batch, int64_t n_rel) {
+    RtkWorkspace w{};
+    unsigned char *p = (unsigned char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *q = p ? p + off : nullptr;
+        off += rtk_align_up(bytes, 256);
+        return q;
+    };
+    w.flags = (uint32_t *)take(256);
+    w.grp_cnt = (int32_t *)take((size_t)n_rel * 8);
+    w.grp_order = (int32_t *)take((size_t)batch * 4);
+    w.grp_work = (int32_t *)take((size_t)(batch / 4 + (n_rel < batch ? n_rel : batch) + 1) * 16);
+    w.grp_qinfo = (int64_t *)take((size_t)batch * 16);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t rtk_relation_tables_bytes(int64_t n_rel, int b, int c) {
+    if (n_rel <= 0 || b <= 0 || c <= 0) return 0;
+    return rtk_align_up((size_t)n_rel * b * c * sizeof(float), 256);
+}
+
+extern "C" size_t rtk_relation_tables_workspace_bytes(int dtype, int64_t n_rel, int a, int b, int c) {
+    if (n_rel <= 0 || a <= 0 || b <= 0 || c <= 0) return 0;
+    return carve_tables(nullptr, dtype, n_rel, a, b, c).total;
+}
+
+extern "C" size_t rtk_from_tables_workspace_bytes(int64_t batch, int64_t n_rel) {
+    if (batch <= 0 || n_rel <= 0) return 0;
+    return carve_ft(nullptr, batch, n_rel).total;
+}
+
+static int check_tables(const char *fn, const void *core, int a, int b, int c, const void *R, int64_t n_rel, float *tables,
+                        void *ws, size_t ws_bytes, int dtype) {
+    RTK_REQUIRE(core && R && tables, RTK_ERR_BAD_ARG, "%s: null operand", fn);
+    RTK_REQUIRE(a > 0 && b > 0 && c > 0 && n_rel > 0, RTK_ERR_BAD_ARG, "%s: sizes must be positive", fn);
+    RTK_REQUIRE(b == c, RTK_ERR_BAD_ARG, "%s: subject rank b=%d must equal object rank c=%d (the reference's view(-1, b) raises otherwise)", fn, b, c);
+    RTK_REQUIRE(n_rel < (1ll << 31), RTK_ERR_UNSUPPORTED, "%s: n_rel exceeds 2^31-1", fn);
+    RTK_REQUIRE((reinterpret_cast<uintptr_t>(tables) & 255) == 0, RTK_ERR_BAD_ARG, "%s: tables must be 256-byte aligned", fn);
+    const size_t need = rtk_relation_tables_workspace_bytes(dtype, n_rel, a, b, c);
+    RTK_REQUIRE(ws && ws_bytes >= need, RTK_ERR_WORKSPACE, "%s: workspace of %zu bytes given, %zu needed", fn, ws_bytes, need);
+    RTK_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, RTK_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", fn);
+    return RTK_OK;
+}
+
+extern "C" int rtk_relation_tables_f32(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
+                                       float *tables, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_tables("rtk_relation_tables_f32", core, a, b, c, R, n_rel, tables, workspace, workspace_bytes, RTK_F32);
+    if (rc != RTK_OK) return rc;
+    return rtk_relation_tables_f32_impl(core, a, b, c, R, n_rel, tables, (hipStream_t)stream);
+}
+
+extern "C" int rtk_relation_tables_bf16(const void *core, int a, int b, int c, const void *R, int64_t n_rel,
+                                        float *tables, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_tables("rtk_relation_tables_bf16", core, a, b, c, R, n_rel, tables, workspace, workspace_bytes, RTK_BF16);
+    if (rc != RTK_OK) return rc;
+    const TablesWs ws = carve_tables(workspace, RTK_BF16, n_rel, a, b, c);
+    return rtk_relation_tables_bf16_impl(core, a, b, c, R, n_rel, tables, ws.core_t, ws.r_packed, (hipStream_t)stream);
+}
+
+static int check_ft(const char *fn, const float *tables, int64_t n_rel, int b, int c, const void *S, int64_t n_sub,
+                    const void *rel_idx, const void *sub_idx, int64_t batch, const void *v_out, const void *q_packed,
+                    void *ws, size_t ws_bytes) {
+    RTK_REQUIRE(tables && S && rel_idx && sub_idx, RTK_ERR_BAD_ARG, "%s: null operand", fn);
+    RTK_REQUIRE(b > 0 && c > 0 && n_rel > 0 && n_sub > 0 && batch > 0, RTK_ERR_BAD_ARG, "%s: sizes must be positive", fn);
+    RTK_REQUIRE(b == c, RTK_ERR_BAD_ARG, "%s: subject rank b=%d must equal object rank c=%d", fn, b, c);
+    RTK_REQUIRE(n_rel < (1ll << 31) && batch < (1ll << 31), RTK_ERR_UNSUPPORTED, "%s: n_rel/batch exceed 2^31-1", fn);
+    RTK_REQUIRE(v_out || q_packed, RTK_ERR_BAD_ARG, "%s: both outputs are NULL", fn);
+    const size_t need = rtk_from_tables_workspace_bytes(batch, n_rel);
+    RTK_REQUIRE(ws && ws_bytes >= need, RTK_ERR_WORKSPACE, "%s: workspace of %zu bytes given, %zu needed", fn, ws_bytes, need);
+    RTK_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, RTK_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", fn);
+    return RTK_OK;
+}
+
+extern "C" int rtk_query_vectors_from_tables_f32(const float *tables, int64_t n_rel, int b, int c, const float *S,
+                                                 int64_t n_sub, const int64_t *rel_idx, const int64_t *sub_idx,
+                                                 int64_t batch, float *v_out, void *q_packed, void *workspace,
+                                                 size_t workspace_bytes, void *stream) {
+    int rc = check_ft("rtk_query_vectors_from_tables_f32", tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out,
+                      q_packed, workspace, workspace_bytes);
+    if (rc != RTK_OK) return rc;
+    return rtk_from_tables_f32_impl(tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed,
+                                    carve_ft(workspace, batch, n_rel), (hipStream_t)stream);
+}
+
+extern "C" int rtk_query_vectors_from_tables_bf16(const float *tables, int64_t n_rel, int b, int c, const void *S,
+                                                  int64_t n_sub, const int64_t *rel_idx, const int64_t *sub_idx,
+                                                  int64_t batch, float *v_out, void *q_packed, void *workspace,
+                                                  size_t workspace_bytes, void *stream) {
+    int rc = check_ft("rtk_query_vectors_from_tables_bf16", tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out,
+                      q_packed, workspace, workspace_bytes);
+    if (rc != RTK_OK) return rc;
+    return rtk_from_tables_bf16_impl(tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed,
+                                     carve_ft(workspace, batch, n_rel), (hipStream_t)stream);
+}
+
+extern "C" int rtk_version(void) { return 200; }
 extern "C" const char *rtk_last_error_string(void) { return g_err; }
 
 extern "C" size_t rtk_workspace_bytes(int dtype, int64_t batch, int64_t n_rel, int a, int b, int c) {
@@ -77,6 +209,8 @@ extern "C" int rtk_read_error_flag(void *workspace, void *stream, uint32_t *host
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemcpyAsync(host_flag_out, workspace, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    // clear on the SAME stream, behind the read: later launches on it start from a clean word
+    if (e == hipSuccess && *host_flag_out) e = hipMemsetAsync(workspace, 0, 4, st);
     if (e != hipSuccess) {
         rtk_set_error("rtk_read_error_flag: %s", hipGetErrorString(e));
         return RTK_ERR_LAUNCH;

@@ -35,6 +35,28 @@ static inline int rtk_check_launch(const char *what) {
     return RTK_OK;
 }
 
+// Kernels that need more than 64 KiB of dynamic LDS must raise hipFuncAttributeMaxDynamicSharedMemorySize,
+// and the attribute is kept PER DEVICE: a process that scores on a second GPU has to set it there too.
+// `done` is a per-instantiation bitmask of device ordinals already configured (atomic: callers may be
+// multi-threaded); devices >= 64 set the attribute on every launch (idempotent).
+#include <atomic>
+static inline int rtk_ensure_dynamic_lds(const void *kernel, int bytes, std::atomic<unsigned long long> &done,
+                                         const char *what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) {
+        const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+        if (bit && (done.load(std::memory_order_acquire) & bit)) return RTK_OK;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) {
+            if (bit) done.fetch_or(bit, std::memory_order_release);
+            return RTK_OK;
+        }
+    }
+    rtk_set_error("%s: cannot reserve %d bytes of dynamic LDS: %s", what, bytes, hipGetErrorString(e));
+    return RTK_ERR_LAUNCH;
+}
+
 static inline size_t rtk_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t rtk_cdiv(int64_t x, int64_t y) { return (x + y - 1) / y; }
 

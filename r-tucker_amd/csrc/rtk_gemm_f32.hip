@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const T *__restrict__ A, int64_t lda, const int32_t *__restrict__ a_rows, bool a_vec,
     const T *__restrict__ B, int64_t ldb, bool b_vec,
     float *__restrict__ C, int64_t ldc, int M, int N, int K,
-    const uint32_t *__restrict__ m_dev, int k_chunk) {
+    const uint32_t *__restrict__ m_dev, int k_chunk, int64_t slab) {
     __shared__ __attribute__((aligned(16))) float As[BK * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
 
@@ -133,15 +133,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         if (B_KMAJOR) store_kmajor(sb, Bs, t); else store_mmajor(sb, Bs, t);
     };
 
-    // split-K: blockIdx.z owns k in [kb, ke); partial sums are combined with float atomics
-    // (C zeroed by the launcher).  k_chunk == 0: the whole K, plain stores.
+    // split-K: blockIdx.z owns k in [kb, ke) and writes its partial tile to slab z of C
+    // (C + z * slab, slab = M * ldc elements); a second kernel adds the slabs in z order, so the
+    // summation order is fixed (no float atomics: run-to-run bit-identical).  k_chunk == 0: the whole K.
     const bool split = k_chunk > 0;
     const int kb = split ? blockIdx.z * k_chunk : 0;
     const int ke = split ? min(K, kb + k_chunk) : K;
-    if (kb >= ke) return;
-    K = ke;
-    load(kb);
-    stash();
+    if (split) C += (int64_t)blockIdx.z * slab;
+    const bool empty = kb >= ke;     // a trailing chunk past K still writes its (zero) slab
+    K = empty ? kb : ke;
+    if (!empty) {
+        load(kb);
+        stash();
+    }
     __syncthreads();
     for (int k0 = kb; k0 < K; k0 += BK) {
         const bool more = k0 + BK < K;
@@ -177,8 +181,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
                 if (m < M && n < N) {
                     float x = acc[i][j][e];
                     if (SIGMOID) x = rtk_sigmoid(x);
-                    if (split) atomicAdd(&C[(int64_t)m * ldc + n], x);
-                    else C[(int64_t)m * ldc + n] = x;
+                    C[(int64_t)m * ldc + n] = x;
                 }
             }
         }
@@ -187,10 +190,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 template <typename T, bool AK, bool BK_, bool SG>
 void launch(const T *A, int64_t lda, const int32_t *a_rows, bool a_vec, const T *B, int64_t ldb,
             bool b_vec, float *C, int64_t ldc, int M, int N, int K, const uint32_t *m_dev,
-            hipStream_t st, int k_chunk = 0) {
-    dim3 grid((unsigned)rtk_cdiv(N, BN), (unsigned)rtk_cdiv(M, BM), (unsigned)(k_chunk > 0 ? rtk_cdiv(K, k_chunk) : 1));
+            hipStream_t st, int k_chunk = 0, int splits = 1, int64_t slab = 0) {
+    dim3 grid((unsigned)rtk_cdiv(N, BN), (unsigned)rtk_cdiv(M, BM), (unsigned)(k_chunk > 0 ? splits : 1));
     hipLaunchKernelGGL((gemm_f32_kernel<T, AK, BK_, SG>), grid, dim3(256), 0, st, A, lda, a_rows, a_vec, B,
-                       ldb, b_vec, C, ldc, M, N, K, m_dev, k_chunk);
+                       ldb, b_vec, C, ldc, M, N, K, m_dev, k_chunk, slab);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -202,14 +205,14 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <typename T>
 static int gemm_dispatch(const T *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const T *B, int b_kmajor,
                          int64_t ldb, float *C, int64_t ldc, int m, int n, int k, bool sg, const uint32_t *m_dev,
-                         hipStream_t st, int k_chunk = 0) {
+                         hipStream_t st, int k_chunk = 0, int splits = 1, int64_t slab = 0) {
     constexpr uintptr_t VA = rtk_vec4_align<T>();
     const bool a_vec = ((reinterpret_cast<uintptr_t>(A) & (VA - 1)) == 0) && (lda % 4 == 0);
     const bool b_vec = ((reinterpret_cast<uintptr_t>(B) & (VA - 1)) == 0) && (ldb % 4 == 0);
 #define RTK_GO(AK, BK_)                                                                                        \
     do {                                                                                                       \
-        if (sg) launch<T, AK, BK_, true>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st, k_chunk);    \
-        else launch<T, AK, BK_, false>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st, k_chunk);      \
+        if (sg) launch<T, AK, BK_, true>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st, k_chunk, splits, slab);    \
+        else launch<T, AK, BK_, false>(A, lda, a_rows, a_vec, B, ldb, b_vec, C, ldc, m, n, k, m_dev, st, k_chunk, splits, slab);      \
     } while (0)
     if (a_kmajor && b_kmajor) RTK_GO(true, true);
     else if (a_kmajor && !b_kmajor) RTK_GO(true, false);
@@ -255,26 +258,65 @@ extern "C" int rtk_score_f32(const float *v, int64_t batch, int c, const float *
                            flags & RTK_SCORE_SIGMOID, nullptr, 0, (hipStream_t)stream);
 }
 
-// Split-K form for short-and-wide products (e.g. dv = dZ . O with K = n_entities): C is zeroed,
-// K is cut into `splits` chunks handled by separate workgroups, partial tiles are added with
-// float atomics (run-to-run summation order is not fixed: last-bit differences between runs).
+namespace {
+// C[i] = sum_z slabs[z * slab + i], z ascending (fixed order); i over M*N contiguous floats
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slabs, int64_t slab, int splits,
+                                                            float *__restrict__ C, int64_t n4, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 acc = reinterpret_cast<const f32x4 *>(slabs)[i];
+        for (int z = 1; z < splits; ++z) {
+            const f32x4 x = reinterpret_cast<const f32x4 *>(slabs + (int64_t)z * slab)[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += x[q];
+        }
+        reinterpret_cast<f32x4 *>(C)[i] = acc;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            float acc = slabs[i];
+            for (int z = 1; z < splits; ++z) acc += slabs[(int64_t)z * slab + i];
+            C[i] = acc;
+        }
+}
+}  // namespace
+
+// Split-K form for short-and-wide products (e.g. dv = dZ . O with K = n_entities): K is cut into
+// `splits` chunks handled by separate workgroups, each writes its partial M x N tile to its own slab
+// of the caller's workspace, and a second kernel adds the slabs in chunk order -- the summation order
+// is a function of the shapes only, so two runs give bit-identical results (no float atomics).
+extern "C" size_t rtk_gemm_f32_splitk_workspace_bytes(int64_t M, int64_t N, int splits) {
+    if (M <= 0 || N <= 0 || splits <= 0) return 0;
+    return rtk_align_up((size_t)M * (size_t)N * sizeof(float), 256) * (size_t)splits;
+}
+
 extern "C" int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda, const float *B, int b_kmajor,
                                    int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int splits,
-                                   void *stream) {
+                                   void *workspace, size_t workspace_bytes, void *stream) {
     RTK_REQUIRE(A && B && C, RTK_ERR_BAD_ARG, "rtk_gemm_f32_splitk: null operand");
     RTK_REQUIRE(M > 0 && N > 0 && K > 0 && splits > 0, RTK_ERR_BAD_ARG, "rtk_gemm_f32_splitk: sizes must be positive");
     RTK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_gemm_f32_splitk: dimension exceeds 2^31-1");
     RTK_REQUIRE(ldc == N, RTK_ERR_BAD_ARG, "rtk_gemm_f32_splitk: C must be contiguous (ldc == N)");
     RTK_REQUIRE(rtk_cdiv(M, BM) <= 65535 && splits <= 65535, RTK_ERR_UNSUPPORTED, "rtk_gemm_f32_splitk: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st);
-    if (e != hipSuccess) {
-        rtk_set_error("rtk_gemm_f32_splitk: memset: %s", hipGetErrorString(e));
-        return RTK_ERR_LAUNCH;
-    }
-    int k_chunk = (int)rtk_cdiv(rtk_cdiv(K, splits), BK) * BK;
-    return gemm_dispatch<float>(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, C, ldc, (int)M, (int)N, (int)K, false,
-                                nullptr, st, k_chunk);
+    if (splits == 1)
+        return gemm_dispatch<float>(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, C, ldc, (int)M, (int)N, (int)K, false,
+                                    nullptr, st);
+    const size_t need = rtk_gemm_f32_splitk_workspace_bytes(M, N, splits);
+    RTK_REQUIRE(workspace && workspace_bytes >= need, RTK_ERR_WORKSPACE,
+                "rtk_gemm_f32_splitk: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    RTK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, RTK_ERR_WORKSPACE, "rtk_gemm_f32_splitk: workspace must be 16-byte aligned");
+    const int64_t slab = (int64_t)(rtk_align_up((size_t)M * (size_t)N * sizeof(float), 256) / sizeof(float));
+    const int k_chunk = (int)rtk_cdiv(rtk_cdiv(K, splits), BK) * BK;
+    int rc = gemm_dispatch<float>(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, (float *)workspace, ldc, (int)M, (int)N,
+                                  (int)K, false, nullptr, st, k_chunk, splits, slab);
+    if (rc != RTK_OK) return rc;
+    const int64_t n = M * N;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) ? n / 4 : 0;
+    const int64_t blocks = n4 > 0 ? rtk_cdiv(n4, 256) : 1;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st,
+                       (const float *)workspace, slab, splits, C, n4, n);
+    return rtk_check_launch("rtk_gemm_f32_splitk");
 }
 
 namespace {

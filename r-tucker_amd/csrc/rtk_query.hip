@@ -642,11 +642,151 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
     }
 }
 
+// ---------------------------------------------------------------- pack ------
+// Packed query planes from fp32 query vectors that were computed elsewhere (entity-sharded scoring with
+// stage 1 split over the ranks: the B x c vectors arrive by all-gather).  Same arithmetic as the tail of
+// the contract kernels: bf16 = round to nearest even, one plane; fp32 = row maximum -> power-of-two
+// scale -> fp16 hi/lo planes.  One workgroup per query row.
+template <bool BF16>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ v, int c, int ksteps,
+                                                        unsigned char *__restrict__ q_packed) {
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    const int64_t d = blockIdx.x;
+    const float *row = v + d * c;
+    unsigned char *tile = q_packed + (d >> 5) * rtk_pack_tile_bytes(ksteps, BF16 ? 1 : 2);
+    const int r = (int)(d & 31);
+    if (BF16) {
+        if (t == 0) reinterpret_cast<float *>(tile)[r] = 1.0f;
+        rtk_bf16 *plane = reinterpret_cast<rtk_bf16 *>(tile + RTK_PACK_HDR);
+        for (int k = t; k < ksteps * 16; k += 256) plane[rtk_pack_offset(ksteps, k, r)] = rtk_f32_to_bf16((k < c) ? row[k] : 0.f);
+        return;
+    }
+    float mx = 0.f;
+    for (int k = t; k < c; k += 256) mx = fmaxf(mx, fabsf(row[k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int sh = rtk_pack_shift(mx);
+    const float up = ldexpf(1.0f, sh);
+    if (t == 0) reinterpret_cast<float *>(tile)[r] = ldexpf(1.0f, -sh);
+    _Float16 *planes = reinterpret_cast<_Float16 *>(tile + RTK_PACK_HDR);
+    for (int k = t; k < ksteps * 16; k += 256) {
+        const float x = (k < c) ? row[k] * up : 0.f;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        const int off = rtk_pack_offset(ksteps, k, r);
+        planes[off] = hi;
+        planes[off + ksteps * 512] = lo;
+    }
+}
+
 }  // namespace
 
 int rtk_gemm_f32_ex(const void *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const void *B,
                     int b_kmajor, int64_t ldb, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                     unsigned flags, const uint32_t *m_dev, int in_bf16, hipStream_t st);
+
+// ---- host side ---------------------------------------------------------------------------------
+// Stage 1 is two steps with a clean interface between them, the relation tables M (n_slots x b x c,
+// fp32): (1) build_tables: M_u = G x_0 R[rel(u)]  -- a function of the PARAMETERS and of which relations
+// are asked for; (2) contract_stage: v_d = S[h_d] . M_{slot(r_d)}.  rtk_query_vectors_* runs both per
+// call (tables of the batch's distinct relations); rtk_relation_tables_* runs (1) once for all
+// relations (slot == relation id) and rtk_query_vectors_from_tables_* runs (2) per batch -- at
+// evaluation time the tables only change when the parameters do.
+
+// (1)  rel_list / n_u_dev: slot -> relation id and device-side slot count (planned batches), or
+// nullptr / nullptr for "slot == relation id, n_u_max slots".  ga.QG > 0: one extra workgroup of the
+// first kernel builds the query groups (costs no launch).  core_t / r_packed: scratch of the bf16
+// large-relation-rank path (transposed core, packed relation rows), may be null otherwise.
+template <typename T>
+static int build_tables(const T *core, int a, int b, int c, const T *R, int64_t n_rel, const int32_t *rel_list,
+                        int n_u_max, const uint32_t *n_u_dev, float *tables, void *core_t, void *r_packed,
+                        const GroupArgs &ga, hipStream_t st) {
+    const int64_t bc = (int64_t)b * c;
+    constexpr int VA = rtk_vec4_align<T>();
+    const unsigned xb = ga.QG > 0 ? 1u : 0u;   // the extra block that builds the groups
+    if (a <= 32) {
+        const bool vec = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(core) & (VA - 1)) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(tables) & 15) == 0);
+        const int W = vec ? 4 : 1;
+        dim3 grid((unsigned)rtk_cdiv(bc, 256 * W) + xb, (unsigned)rtk_cdiv(n_u_max, UT));
+        RTK_REQUIRE(grid.y <= 65535, RTK_ERR_UNSUPPORTED, "relation tables: more than %d relations per launch", 65535 * UT);
+        if (vec) hipLaunchKernelGGL((tables_kernel<T, true>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, tables, ga);
+        else hipLaunchKernelGGL((tables_kernel<T, false>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, tables, ga);
+    } else if (sizeof(T) == 2 && core_t && r_packed) {
+        // bf16, a <= 512: transpose the core, pack the relation rows, run the bf16 MFMA score kernel
+        // with (queries, entities, K) := (relation slots, (b,c) pairs, a); raw fp32 output = the tables
+        const int ks_a = (a + 15) / 16;
+        dim3 tg((unsigned)rtk_cdiv(bc, 64) + xb, (unsigned)rtk_cdiv(a, 64));
+        hipLaunchKernelGGL(transpose_core_kernel, tg, dim3(256), 0, st, (const rtk_bf16 *)core, a, bc, (rtk_bf16 *)core_t, ga);
+        const int rows_padded = (int)rtk_cdiv(n_u_max, 32) * 32;
+        hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded), dim3(256), 0, st, (const rtk_bf16 *)R, a,
+                           (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)r_packed, ks_a);
+        int rc = rtk_score_packed_bf16(r_packed, n_u_max, a, core_t, bc, tables, bc, 0, (void *)st);
+        if (rc != RTK_OK) return rc;
+    } else {
+        // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM (bf16 operands widen on load)
+        if (xb) hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(256), 0, st, ga);
+        int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, tables, bc, n_u_max, bc, a, 0, n_u_dev,
+                                 sizeof(T) == 2, st);
+        if (rc != RTK_OK) return rc;
+    }
+    return rtk_check_launch("relation tables");
+}
+
+struct ContractPlan {   // host-side choices of step (2), needed before step (1) (the groups ride in its first kernel)
+    bool grouped, cvec;
+    int QG;
+    size_t smem_grouped;
+};
+static ContractPlan plan_contract(int b, int c, int64_t batch, const float *tables) {
+    ContractPlan p;
+    p.cvec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(tables) & 15) == 0);
+    const int cW = p.cvec ? 4 : 1;
+    const int ccols = (c + cW - 1) / cW;
+    p.QG = batch >= 2048 ? 8 : 4;
+    p.smem_grouped = ccols <= 256
+        ? (size_t)((size_t)p.QG * ((b + 3) & ~3) + (size_t)p.QG * (256 / ccols) * ccols * cW) * sizeof(float) : (size_t)-1;
+    static const int force = [] {   // RTK_CONTRACT=perquery|grouped: A/B comparisons
+        const char *e = getenv("RTK_CONTRACT");
+        return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'g' ? 2 : 0));
+    }();
+    p.grouped = p.smem_grouped <= 64 * 1024 && force != 1 && (batch >= 2048 || force == 2);
+    return p;
+}
+
+// (2)  slot_of_rel: relation id -> table slot (planned batches) or nullptr for slot == relation id.
+// have_groups: the slot order of the queries (grp_order / grp_work / grp_qinfo, flags[2]) was built.
+template <typename T>
+static int contract_stage(const float *tables, int b, int c, const T *S, int64_t n_sub, const int64_t *rel_idx,
+                          const int64_t *sub_idx, int64_t n_rel, int64_t batch, const int32_t *slot_of_rel,
+                          int n_slots, const ContractPlan &cp, bool have_groups, const int32_t *grp_work,
+                          const int32_t *grp_order, const int64_t *grp_qinfo, uint32_t *flags, float *v_out,
+                          void *q_packed, hipStream_t st) {
+    const int ksteps = (c + 15) / 16;
+    if (cp.grouped) {
+        RTK_REQUIRE(have_groups, RTK_ERR_BAD_ARG, "rtk_query_vectors: grouped contract without groups");
+        const unsigned nwg = (unsigned)(batch / cp.QG + (n_slots < batch ? n_slots : batch) + 8);   // upper bound on the work items, rounded up to 8 (flags[2] holds the count)
+#define RTK_CG(V_, Q_) hipLaunchKernelGGL((contract_grouped_kernel<T, V_, Q_>), dim3(nwg), dim3(256), cp.smem_grouped, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, grp_work, grp_order, v_out, (unsigned char *)q_packed, ksteps, flags)
+        if (cp.cvec) { if (cp.QG == 8) RTK_CG(true, 8); else RTK_CG(true, 4); }
+        else { if (cp.QG == 8) RTK_CG(false, 8); else RTK_CG(false, 4); }
+#undef RTK_CG
+        return rtk_check_launch("rtk_query_vectors");
+    }
+    const int W = cp.cvec ? 4 : 1;
+    const int cols = (c + W - 1) / W;
+    const int ngroups = cols >= 256 ? 1 : 256 / cols;
+    const size_t smem = (size_t)ngroups * cols * W * sizeof(float);
+    RTK_REQUIRE(smem <= 64 * 1024, RTK_ERR_UNSUPPORTED, "rtk_query_vectors: rank too large for the contract kernel (b=%d c=%d)", b, c);
+    const int64_t *pq_order = have_groups ? grp_qinfo : nullptr;
+    const unsigned pq_grid = (unsigned)(have_groups ? rtk_cdiv(batch, 8) * 8 : batch);
+    if (cp.cvec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3(pq_grid), dim3(256), smem, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, slot_of_rel, v_out, (unsigned char *)q_packed, ksteps, flags, pq_order, (int)batch);
+    else hipLaunchKernelGGL((contract_kernel<T, false>), dim3(pq_grid), dim3(256), smem, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, slot_of_rel, v_out, (unsigned char *)q_packed, ksteps, flags, pq_order, (int)batch);
+    return rtk_check_launch("rtk_query_vectors");
+}
 
 // Enqueue stage 1.  `ws` already carved (rtk_abi.hip).  T = float or rtk_bf16 (operands);
 // tables, accumulation and v_out are fp32 either way.
@@ -654,7 +794,6 @@ template <typename T>
 static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, int64_t n_rel, const T *S,
                               int64_t n_sub, const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
                               float *v_out, void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
-    const int64_t bc = (int64_t)b * c;
     const bool planned = n_rel > batch;  // otherwise: one table per relation id, slot == id
     const int n_u_max = (int)(planned ? batch : n_rel);
     // the error word (flags[0]) is sticky and owned by the caller: zeroed at workspace creation
@@ -663,71 +802,44 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, rel_idx, (int)batch, (int)n_rel,
                            ws.slot_of_rel, ws.rel_list, ws.flags);
     }
-    const int32_t *rel_list = planned ? ws.rel_list : nullptr;
-    const uint32_t *n_u_dev = planned ? ws.flags + 1 : nullptr;
-    constexpr int VA = rtk_vec4_align<T>();
-    // contract kernel: grouped by table slot when its tile fits (QG queries share every table row)
-    const bool cvec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws.tables) & 15) == 0);
-    const int cW = cvec ? 4 : 1;
-    const int ccols = (c + cW - 1) / cW;
-    const int QG = batch >= 2048 ? 8 : 4;
-    const size_t smem_grouped = ccols <= 256
-        ? (size_t)((size_t)QG * ((b + 3) & ~3) + (size_t)QG * (256 / ccols) * ccols * cW) * sizeof(float) : (size_t)-1;
-    static const int force = [] {   // RTK_CONTRACT=perquery|grouped: A/B comparisons
-        const char *e = getenv("RTK_CONTRACT");
-        return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'g' ? 2 : 0));
-    }();
-    const bool grouped = smem_grouped <= 64 * 1024 && force != 1 && (batch >= 2048 || force == 2);
+    const ContractPlan cp = plan_contract(b, c, batch, ws.tables);
     // the slot order is built either way: the per-query kernel uses it to keep a table in one XCD's L2
-    const bool build = batch < (1ll << 31);
     GroupArgs ga{rel_idx, planned ? ws.slot_of_rel : nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
-                 (int)batch, (int)n_rel, n_u_max, build ? QG : 0, sub_idx, ws.grp_qinfo};
-    const unsigned xb = build ? 1u : 0u;   // the extra block that builds the groups
-    if (a <= 32) {
-        const bool vec = (bc % 4 == 0) && ((reinterpret_cast<uintptr_t>(core) & (VA - 1)) == 0);
-        const int W = vec ? 4 : 1;
-        dim3 grid((unsigned)rtk_cdiv(bc, 256 * W) + xb, (unsigned)rtk_cdiv(n_u_max, UT));
-        if (vec) hipLaunchKernelGGL((tables_kernel<T, true>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables, ga);
-        else hipLaunchKernelGGL((tables_kernel<T, false>), grid, dim3(256), 0, st, core, a, bc, R, rel_list, n_u_max, n_u_dev, ws.tables, ga);
-    } else if (sizeof(T) == 2 && ws.core_t && ws.r_packed) {
-        // bf16, a <= 512: transpose the core, pack the relation rows, run the bf16 MFMA score kernel
-        // with (queries, entities, K) := (relation slots, (b,c) pairs, a); raw fp32 output = the tables
-        const int ks_a = (a + 15) / 16;
-        dim3 tg((unsigned)rtk_cdiv(bc, 64) + xb, (unsigned)rtk_cdiv(a, 64));
-        hipLaunchKernelGGL(transpose_core_kernel, tg, dim3(256), 0, st, (const rtk_bf16 *)core, a, bc, (rtk_bf16 *)ws.core_t, ga);
-        const int rows_padded = (int)rtk_cdiv(n_u_max, 32) * 32;
-        hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded), dim3(256), 0, st, (const rtk_bf16 *)R, a,
-                           (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)ws.r_packed, ks_a);
-        int rc = rtk_score_packed_bf16(ws.r_packed, n_u_max, a, ws.core_t, bc, ws.tables, bc, 0, (void *)st);
-        if (rc != RTK_OK) return rc;
-    } else {
-        // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM (bf16 operands widen on load)
-        if (build) hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(256), 0, st, ga);
-        int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, ws.tables, bc, n_u_max, bc, a, 0, n_u_dev,
-                                 sizeof(T) == 2, st);
-        if (rc != RTK_OK) return rc;
+                 (int)batch, (int)n_rel, n_u_max, cp.QG, sub_idx, ws.grp_qinfo};
+    int rc = build_tables<T>(core, a, b, c, R, n_rel, planned ? ws.rel_list : nullptr, n_u_max,
+                             planned ? ws.flags + 1 : nullptr, ws.tables, ws.core_t, ws.r_packed, ga, st);
+    if (rc != RTK_OK) return rc;
+    return contract_stage<T>(ws.tables, b, c, S, n_sub, rel_idx, sub_idx, n_rel, batch,
+                             planned ? ws.slot_of_rel : nullptr, n_u_max, cp, true, ws.grp_work, ws.grp_order,
+                             ws.grp_qinfo, ws.flags, v_out, q_packed, st);
+}
+
+// Tables of ALL relations, slot == relation id (rtk_relation_tables_*).
+template <typename T>
+static int relation_tables_impl(const T *core, int a, int b, int c, const T *R, int64_t n_rel, float *tables,
+                                void *core_t, void *r_packed, hipStream_t st) {
+    GroupArgs ga{};   // QG = 0: no groups
+    return build_tables<T>(core, a, b, c, R, n_rel, nullptr, (int)n_rel, nullptr, tables, core_t, r_packed, ga, st);
+}
+
+// Step (2) alone against prebuilt tables (rtk_query_vectors_from_tables_*).  ws: the small "from
+// tables" workspace (rtk_abi.hip::carve_ft).  The grouped kernel (batch >= 2048) needs the slot order
+// of the queries: one single-workgroup launch; the per-query kernel runs without it (one launch
+// instead of two: at B = 512 the order is worth 1.8 us of L2 locality, a launch costs more).
+template <typename T>
+static int from_tables_impl(const float *tables, int64_t n_rel, int b, int c, const T *S, int64_t n_sub,
+                            const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
+                            void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
+    const ContractPlan cp = plan_contract(b, c, batch, tables);
+    static const bool order_small = getenv("RTK_FT_ORDER") != nullptr;   // A/B: slot order for the per-query kernel too
+    const bool groups = cp.grouped || order_small;
+    if (groups) {
+        GroupArgs ga{rel_idx, nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
+                     (int)batch, (int)n_rel, (int)n_rel, cp.QG, sub_idx, ws.grp_qinfo};
+        hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(256), 0, st, ga);
     }
-    const int ksteps_g = (c + 15) / 16;
-    if (grouped) {
-        const unsigned nwg = (unsigned)(batch / QG + n_u_max + 8);   // upper bound on the work items, rounded up to 8 (flags[2] holds the count)
-#define RTK_CG(V_, Q_) hipLaunchKernelGGL((contract_grouped_kernel<T, V_, Q_>), dim3(nwg), dim3(256), smem_grouped, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, ws.grp_work, ws.grp_order, v_out, (unsigned char *)q_packed, ksteps_g, ws.flags)
-        if (cvec) { if (QG == 8) RTK_CG(true, 8); else RTK_CG(true, 4); }
-        else { if (QG == 8) RTK_CG(false, 8); else RTK_CG(false, 4); }
-#undef RTK_CG
-        return rtk_check_launch("rtk_query_vectors");
-    }
-    const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws.tables) & 15) == 0);
-    const int W = vec ? 4 : 1;
-    const int cols = (c + W - 1) / W;
-    const int ngroups = cols >= 256 ? 1 : 256 / cols;
-    const size_t smem = (size_t)ngroups * cols * W * sizeof(float);
-    RTK_REQUIRE(smem <= 64 * 1024, RTK_ERR_UNSUPPORTED, "rtk_query_vectors: rank too large for the contract kernel (b=%d c=%d)", b, c);
-    const int ksteps = (c + 15) / 16;
-    const int64_t *pq_order = build ? ws.grp_qinfo : nullptr;
-    const unsigned pq_grid = (unsigned)(build ? rtk_cdiv(batch, 8) * 8 : batch);
-    if (vec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3(pq_grid), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags, pq_order, (int)batch);
-    else hipLaunchKernelGGL((contract_kernel<T, false>), dim3(pq_grid), dim3(256), smem, st, ws.tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, planned ? ws.slot_of_rel : nullptr, v_out, (unsigned char *)q_packed, ksteps, ws.flags, pq_order, (int)batch);
-    return rtk_check_launch("rtk_query_vectors");
+    return contract_stage<T>(tables, b, c, S, n_sub, rel_idx, sub_idx, n_rel, batch, nullptr, (int)n_rel, cp, groups,
+                             ws.grp_work, ws.grp_order, ws.grp_qinfo, ws.flags, v_out, q_packed, st);
 }
 
 int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
@@ -743,4 +855,41 @@ int rtk_query_vectors_bf16_impl(const void *core, int a, int b, int c, const voi
                                 const RtkWorkspace &ws, hipStream_t st) {
     return query_vectors_impl<rtk_bf16>((const rtk_bf16 *)core, a, b, c, (const rtk_bf16 *)R, n_rel,
                                         (const rtk_bf16 *)S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed, ws, st);
+}
+
+int rtk_relation_tables_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel, float *tables,
+                                 hipStream_t st) {
+    return relation_tables_impl<float>(core, a, b, c, R, n_rel, tables, nullptr, nullptr, st);
+}
+
+int rtk_relation_tables_bf16_impl(const void *core, int a, int b, int c, const void *R, int64_t n_rel, float *tables,
+                                  void *core_t, void *r_packed, hipStream_t st) {
+    return relation_tables_impl<rtk_bf16>((const rtk_bf16 *)core, a, b, c, (const rtk_bf16 *)R, n_rel, tables, core_t,
+                                          r_packed, st);
+}
+
+int rtk_from_tables_f32_impl(const float *tables, int64_t n_rel, int b, int c, const float *S, int64_t n_sub,
+                             const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
+                             void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
+    return from_tables_impl<float>(tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed, ws, st);
+}
+
+int rtk_from_tables_bf16_impl(const float *tables, int64_t n_rel, int b, int c, const void *S, int64_t n_sub,
+                              const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
+                              void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
+    return from_tables_impl<rtk_bf16>(tables, n_rel, b, c, (const rtk_bf16 *)S, n_sub, rel_idx, sub_idx, batch, v_out,
+                                      q_packed, ws, st);
+}
+
+extern "C" int rtk_pack_query_vectors(const float *v, int64_t batch, int c, int dtype, void *q_packed, void *stream) {
+    RTK_REQUIRE(v && q_packed, RTK_ERR_BAD_ARG, "rtk_pack_query_vectors: null operand");
+    RTK_REQUIRE(batch > 0 && c > 0 && batch < (1ll << 31), RTK_ERR_BAD_ARG, "rtk_pack_query_vectors: bad sizes");
+    RTK_REQUIRE(dtype == RTK_F32 || dtype == RTK_BF16, RTK_ERR_BAD_ARG, "rtk_pack_query_vectors: dtype");
+    RTK_REQUIRE(c <= 512, RTK_ERR_UNSUPPORTED, "rtk_pack_query_vectors: c=%d > 512 has no packed score kernel", c);
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = (c + 15) / 16;
+    // rows of the last tile beyond `batch` stay unwritten: the score kernels never store them
+    if (dtype == RTK_BF16) hipLaunchKernelGGL(pack_rows_kernel<true>, dim3((unsigned)batch), dim3(256), 0, st, v, c, ks, (unsigned char *)q_packed);
+    else hipLaunchKernelGGL(pack_rows_kernel<false>, dim3((unsigned)batch), dim3(256), 0, st, v, c, ks, (unsigned char *)q_packed);
+    return rtk_check_launch("rtk_pack_query_vectors");
 }

@@ -192,14 +192,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
 }
 
 template <int KS, int SG, int MINW, int NW, bool NTS, bool OBF>
-void launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
-                hipStream_t st) {
+int launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
+              hipStream_t st) {
     constexpr size_t tile = RTK_PACK_HDR + KS * 1024, smem = 2 * tile;
-    static bool attr_set = false;
-    if (smem > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (smem > 64 * 1024) {
+        const int rc = rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF>),
+                                              (int)smem, lds_ok, "score_bf16_kernel");
+        if (rc != RTK_OK) return rc;
     }
     const int n_mt = (int)rtk_cdiv(B, 32);
     static const int qb_kb = getenv("RTK_BF16_QB_KB") ? atoi(getenv("RTK_BF16_QB_KB")) : 3072;   // A/B: block size of the sweep
@@ -212,10 +212,11 @@ void launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, 
     const int64_t units = rtk_cdiv(N, 32 * NW) * (int64_t)qb;
     const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
     hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
+    return RTK_OK;
 }
 
 template <int KS, int SG, int MINW, int NW>
-void launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
+int launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
                 bool obf, hipStream_t st) {
     static const bool nts_off = getenv("RTK_NO_NT_STORES") != nullptr;
     const bool nts = !nts_off && (ld * (obf ? 2 : 4)) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
@@ -228,24 +229,24 @@ void launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c,
     if constexpr (SG != 1) {   // (the exact-logistic variant keeps one form)
         if (nts) return launch_nt<KS, SG, MINW, NW, true, false>(qp, B, O, N, c, out, ld, o_vec, st);
     }
-    launch_nt<KS, SG, MINW, NW, false, false>(qp, B, O, N, c, out, ld, o_vec, st);
+    return launch_nt<KS, SG, MINW, NW, false, false>(qp, B, O, N, c, out, ld, o_vec, st);
 }
 
 template <int KS, int MINW, int NW>
-void launch_ks(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, int sg,
-               bool o_vec, bool obf, hipStream_t st) {
-    if (sg == 0) launch_one<KS, 0, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
-    else if (sg == 1) launch_one<KS, 1, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
-    else launch_one<KS, 2, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
+int launch_ks(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, int sg,
+              bool o_vec, bool obf, hipStream_t st) {
+    if (sg == 0) return launch_one<KS, 0, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
+    if (sg == 1) return launch_one<KS, 1, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
+    return launch_one<KS, 2, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
 }
 
 template <int KS, int MINW>
-void launch_shape(bool wide, const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld,
+int launch_shape(bool wide, const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld,
                   int sg, bool o_vec, bool obf, hipStream_t st) {
     if constexpr (KS > 16) {
         if (wide) return launch_ks<KS, 1, 8>(qp, B, O, N, c, out, ld, sg, o_vec, obf, st);
     }
-    launch_ks<KS, MINW, 4>(qp, B, O, N, c, out, ld, sg, o_vec, obf, st);
+    return launch_ks<KS, MINW, 4>(qp, B, O, N, c, out, ld, sg, o_vec, obf, st);
 }
 
 }  // namespace
@@ -271,7 +272,8 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
     // 8-wave workgroups (256 entities share a staged query tile) once the problem fills the chip that way
     static const bool narrow = getenv("RTK_BF16_NARROW") != nullptr;   // A/B: 4-wave workgroups, two per CU
     const bool wide = !narrow && ks > 16 && rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256;
-#define RTK_KS(K_, W_) case K_: launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, obf, st); break;
+#define RTK_KS(K_, W_) case K_: rc = launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, obf, st); break;
+    int rc = RTK_OK;
     switch (ks) {
         RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
         RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)
@@ -282,5 +284,6 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
             return RTK_ERR_UNSUPPORTED;
     }
 #undef RTK_KS
+    if (rc != RTK_OK) return rc;
     return rtk_check_launch("rtk_score_packed_bf16");
 }

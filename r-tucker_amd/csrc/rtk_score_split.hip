@@ -26,47 +26,46 @@ using rtk_split::score_split_kernel;
 namespace {
 
 template <int KS, int SG, int MINW>
-void launch_one(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
+int launch_one(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                 bool o_vec, unsigned grid, hipStream_t st) {
     constexpr size_t smem = 2 * (size_t)(RTK_PACK_HDR + 2 * KS * 1024);
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the attribute (idempotent)
-    if (smem > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_split_kernel<KS, SG, MINW, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (smem > 64 * 1024) {
+        const int rc = rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&score_split_kernel<KS, SG, MINW, 0>), (int)smem,
+                                              lds_ok, "score_split_kernel");
+        if (rc != RTK_OK) return rc;
     }
     hipLaunchKernelGGL((score_split_kernel<KS, SG, MINW, 0>), dim3(grid), dim3(256), smem, st, qp, B, O, N, c,
                        out, ld, o_vec);
+    return RTK_OK;
 }
 
 template <int KS, int MINW>
-void launch_ks(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
+int launch_ks(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                int sigmoid, bool o_vec, hipStream_t st) {
     // one block per resident slot (256 CUs x MINW workgroups); the kernel splits the
     // linearised (entity tile, query tile) space evenly over them
     const int64_t units = rtk_cdiv(N, 128) * rtk_cdiv(B, 32);
     const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
-    if (sigmoid == 0) launch_one<KS, 0, MINW>(qp, B, O, N, c, out, ld, o_vec, grid, st);
-    else if (sigmoid == 1) launch_one<KS, 1, MINW>(qp, B, O, N, c, out, ld, o_vec, grid, st);
-    else launch_one<KS, 2, MINW>(qp, B, O, N, c, out, ld, o_vec, grid, st);
+    if (sigmoid == 0) return launch_one<KS, 0, MINW>(qp, B, O, N, c, out, ld, o_vec, grid, st);
+    if (sigmoid == 1) return launch_one<KS, 1, MINW>(qp, B, O, N, c, out, ld, o_vec, grid, st);
+    return launch_one<KS, 2, MINW>(qp, B, O, N, c, out, ld, o_vec, grid, st);
 }
 
 }  // namespace
 
-bool rtk_score_ws_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
-                         int sg, bool o_vec, hipStream_t st);
-bool rtk_score_ws2_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
-                          int sg, bool o_vec, hipStream_t st);
+int rtk_score_ws_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
+                        int sg, bool o_vec, hipStream_t st);
 
 // Default: the persistent wave-specialised kernel (ws), then the two-workgroups-per-CU kernel (v3)
-// for the shapes ws does not cover.  RTK_SCORE_KERNEL=v3 forces v3; =ws2 tries the two-tiles-per-
-// barrier variant first (A/B comparisons: measured slower than ws at the WN18RR shape, 53.9 vs
-// 48.5 us -- its helper waves' store bursts stall longer, tools/ablate/run_ws2.py).
+// for the shapes ws does not cover.  RTK_SCORE_KERNEL=v3 forces v3 (A/B comparisons).  (The
+// two-tiles-per-barrier variant "ws2" was measured slower, 53.9 vs 48.5 us at the WN18RR shape, and
+// lives in tools/ablate/ only.)
 static int kernel_choice() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("RTK_SCORE_KERNEL");
-        v = (e && e[0] == 'v' && e[1] == '3') ? 0 : (e && e[0] == 'w' && e[1] == 's' && e[2] == '2') ? 2 : 1;
+        v = (e && e[0] == 'v' && e[1] == '3') ? 0 : 1;
     }
     return v;
 }
@@ -91,14 +90,16 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
     const bool o_vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
     const int B = (int)batch, N = (int)n_local;
     const unsigned char *qp = (const unsigned char *)q_packed;
-    if (kernel_choice() >= 2 && rtk_score_ws2_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st))
-        return rtk_check_launch("rtk_score_packed_f32");
-    if (kernel_choice() >= 1 && rtk_score_ws_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st))
-        return rtk_check_launch("rtk_score_packed_f32");
+    if (kernel_choice() >= 1) {
+        const int took = rtk_score_ws_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st);
+        if (took < 0) return took;
+        if (took) return rtk_check_launch("rtk_score_packed_f32");
+    }
+    int rc = RTK_OK;
     // the packed planes were written for exactly `ks` k-steps (tile stride), so the
     // instantiation must match exactly.
 #define RTK_KS(K_, W_) \
-    case K_: launch_ks<K_, W_>(qp, B, O, N, c, out, ld_out, sg, o_vec, st); break;
+    case K_: rc = launch_ks<K_, W_>(qp, B, O, N, c, out, ld_out, sg, o_vec, st); break;
     switch (ks) {
         RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
         RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)
@@ -112,5 +113,6 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
             return RTK_ERR_UNSUPPORTED;
     }
 #undef RTK_KS
+    if (rc != RTK_OK) return rc;
     return rtk_check_launch("rtk_score_packed_f32");
 }

@@ -26,8 +26,13 @@
 
 namespace rtk_ws {
 
-// tools/ablate only: cycle stamps (STAMP template flag)
+// tools/ablate only: cycle stamps (STAMP template flag).  The 131 KB stamp array exists only in the
+// ablation build (-DRTK_ABLATE_STAMPS); in the product library every use below is dead code (STAMP = false).
+#ifdef RTK_ABLATE_STAMPS
 __device__ unsigned long long g_ws_stamps[256 * 8 * 8];
+#else
+static constexpr unsigned long long *g_ws_stamps = nullptr;
+#endif
 
 constexpr int EX_BYTES = 4 * 4 * 64 * 16;  // one exchange buffer: 4 M waves x 16 accumulator regs x 64 lanes x f32
 
@@ -328,26 +333,16 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
                     out + (int64_t)mt * 32 * ld_out, 0, (unsigned)(rows * ld_out * 4), 0x00020000);
                 // stage by stage over all 16 values: written element by element the compiler chains
                 // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
-                float zz[16], dd[16], pp[16];
+                float zz[16], pp[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 z = exr[g * 64 + lane];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q];
                 }
-                if (false) {   // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
+                // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) zz[e] = fminf(zz[e] * -1.4426950408889634f, 126.0f);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) dd[e] = 1.0f + __builtin_amdgcn_exp2f(zz[e]);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) pp[e] = __builtin_amdgcn_rcpf(dd[e]);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) pp[e] = fmaf(pp[e], fmaf(-dd[e], pp[e], 1.0f), pp[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
-                }
+                for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
                 unsigned off = voff;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {

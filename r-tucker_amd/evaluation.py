@@ -123,8 +123,10 @@ def metrics_from_ranks(ranks: torch.Tensor):
 def evaluate(model, dataset, batch_size=512, device=None, flt: DeviceFilter = None):
     """The reference's ``evaluate`` loop on the device.  ``dataset``: a test-mode ``KG_dataset``.
     Returns (metrics dict averaged over queries, mean BCE loss) like train.py:123-125."""
+    from .ops import check_device_errors, index_check
     device = torch.device(device) if device is not None else next(model.parameters()).device
     flt = flt or DeviceFilter(dataset, device)
+    model.eval()          # train.py:96; also drops the relation-table cache: the tables are rebuilt once, below
     if hasattr(model, "E"):
         T = SFTucker(model.core.data, [model.R.weight], num_shared_factors=2, shared_factor=model.E.weight)
     else:
@@ -134,18 +136,21 @@ def evaluate(model, dataset, batch_size=512, device=None, flt: DeviceFilter = No
     acc = torch.zeros(5, dtype=torch.float64, device=device)   # running sums on the device: one sync at the end
     loss_terms = 0
     n_batches = 0
-    for lo in range(0, n, batch_size):
-        hi = min(lo + batch_size, n)
-        ids = torch.arange(lo, hi, device=device)
-        f = flt.features[lo:hi]
-        P = model(f[:, 0], f[:, 1])(T)
-        ranks, bce = filtered_ranks(P, f[:, 2], flt, ids, want_bce=True)
-        # the reference averages the per-batch MEAN losses (train.py:113,125): scale this batch's row sums
-        bce.mul_(1.0 / (P.shape[0] * P.shape[1]))
-        with torch.cuda.device(device):
-            _lib.check(lib.rtk_rank_metrics_f64(ranks.data_ptr(), bce.data_ptr(), hi - lo, acc.data_ptr(),
-                                                torch.cuda.current_stream(device).cuda_stream), "rtk_rank_metrics_f64")
-        n_batches += 1
+    # out-of-range ids: checked once, at the loop's own synchronisation point below (reference: IndexError)
+    with index_check("deferred"):
+        for lo in range(0, n, batch_size):
+            hi = min(lo + batch_size, n)
+            ids = torch.arange(lo, hi, device=device)
+            f = flt.features[lo:hi]
+            P = model(f[:, 0], f[:, 1])(T)       # eval mode + no_grad: relation tables built once, reused by every batch
+            ranks, bce = filtered_ranks(P, f[:, 2], flt, ids, want_bce=True)
+            # the reference averages the per-batch MEAN losses (train.py:113,125): scale this batch's row sums
+            bce.mul_(1.0 / (P.shape[0] * P.shape[1]))
+            with torch.cuda.device(device):
+                _lib.check(lib.rtk_rank_metrics_f64(ranks.data_ptr(), bce.data_ptr(), hi - lo, acc.data_ptr(),
+                                                    torch.cuda.current_stream(device).cuda_stream), "rtk_rank_metrics_f64")
+            n_batches += 1
     acc = acc.cpu().tolist()
+    check_device_errors(device)
     sums = {"mrr": acc[0] / n, "hits@1": acc[1] / n, "hits@3": acc[2] / n, "hits@10": acc[3] / n}
     return sums, acc[4] / n_batches

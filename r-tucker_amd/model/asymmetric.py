@@ -13,9 +13,10 @@ import torch
 from torch import nn
 
 from ..ops import score_1vN
+from ._tables import TablesCacheMixin
 
 
-class R_TuckER(nn.Module):
+class R_TuckER(TablesCacheMixin, nn.Module):
     def __init__(self, data_count, rank=None, **kwargs):
         super().__init__()
         n_ent, n_rel = data_count
@@ -24,10 +25,12 @@ class R_TuckER(nn.Module):
         self.O = nn.Embedding(n_ent, rank[2])
         self.core = nn.Parameter(torch.zeros(tuple(rank), dtype=torch.float32))
         self.rank = rank
+        self._tables_reset()
 
     def init(self, state_dict=None):
         """Load a state dict, or Xavier-initialise and orthonormalise the factor
         columns by thin QR (reference: R_TuckER.py:27-39)."""
+        self._tables_reset()
         if state_dict:
             self.load_state_dict(state_dict)
             return
@@ -42,6 +45,7 @@ class R_TuckER(nn.Module):
         def score_fn(T):
             # sizes, dtype and device come from T, never from self.rank: during training
             # T is the doubled-rank tangent-space construct
-            return score_1vN(T.core, T.factors[0], T.factors[1], T.factors[2], subject_idx, relation_idx)
+            tables = self._cached_tables(T.core, T.factors[0])
+            return score_1vN(T.core, T.factors[0], T.factors[1], T.factors[2], subject_idx, relation_idx, tables=tables)
 
         return score_fn

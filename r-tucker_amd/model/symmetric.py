@@ -11,9 +11,10 @@ import torch
 from torch import nn
 
 from ..ops import score_1vN
+from ._tables import TablesCacheMixin
 
 
-class R_TuckER(nn.Module):
+class R_TuckER(TablesCacheMixin, nn.Module):
     def __init__(self, data_count, rank=None, **kwargs):
         super().__init__()
         n_ent, n_rel = data_count
@@ -21,8 +22,10 @@ class R_TuckER(nn.Module):
         self.R = nn.Embedding(n_rel, rank[0])
         self.core = nn.Parameter(torch.zeros(tuple(rank), dtype=torch.float32))
         self.rank = rank
+        self._tables_reset()
 
     def init(self, state_dict=None):
+        self._tables_reset()
         if state_dict:
             self.load_state_dict(state_dict)
             return
@@ -36,6 +39,7 @@ class R_TuckER(nn.Module):
     def forward(self, subject_idx, relation_idx):
         def score_fn(T):
             E = T.shared_factor
-            return score_1vN(T.core, T.regular_factors[0], E, E, subject_idx, relation_idx)
+            tables = self._cached_tables(T.core, T.regular_factors[0])
+            return score_1vN(T.core, T.regular_factors[0], E, E, subject_idx, relation_idx, tables=tables)
 
         return score_fn

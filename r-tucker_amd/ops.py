@@ -73,21 +73,99 @@ def _idx(name, t, device):
 
 
 def _workspace(device, stream_ptr, nbytes):
+    """The caller-owned scratch of the C ABI, one per (device, stream).  Its 256-byte header holds the
+    sticky device error word (include/rtucker_hip.h); when the buffer has to grow the header is carried
+    over, so an out-of-range id seen before the regrow is still reported.  Called with the owning
+    stream current, so the header copy is ordered behind the kernels that may have set the word."""
     key = (device.index, stream_ptr)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        ws[:256].zero_()   # header: sticky error word, owned by the caller (include/rtucker_hip.h)
-        _workspaces[key] = ws
+        new = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if ws is None:
+            new[:256].zero_()
+        else:
+            new[:256].copy_(ws[:256])
+        _workspaces[key] = ws = new
     return ws
+
+
+# What happens when a kernel meets an out-of-range subject / relation id (the kernels clamp it and raise
+# a sticky flag; the reference raises IndexError, SURVEY.md section 8b "Errors"):
+#   "strict"   (default) every scoring call reads the flag back before returning -> IndexError like the
+#              reference, at the price of one stream synchronisation per call;
+#   "deferred" nothing per call; ``check_device_errors()`` raises at the caller's own sync point
+#              (``evaluate()`` and the training driver do that once per loop);
+#   "off"      never checked (graph capture, benchmarks).
+# Calls made while the stream is being captured into a HIP graph are never synchronised.
+INDEX_CHECK = os.environ.get("R_TUCKER_AMD_INDEX_CHECK", "strict")
+
+
+class index_check:
+    """Context manager / setter for the out-of-range-id policy: ``with index_check("deferred"): ...``."""
+
+    def __init__(self, mode):
+        if mode not in ("strict", "deferred", "off"):
+            raise ValueError(f"index check mode must be strict | deferred | off, got {mode!r}")
+        self.mode = mode
+
+    def __enter__(self):
+        global INDEX_CHECK
+        self.prev, INDEX_CHECK = INDEX_CHECK, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global INDEX_CHECK
+        INDEX_CHECK = self.prev
+        return False
+
+
+def _check_now(ws, sp):
+    """Read (and clear) the error word of one workspace on its own stream; raise like torch's indexing."""
+    flag = C.c_uint32(0)
+    _lib.check(_lib.load().rtk_read_error_flag(ws.data_ptr(), sp, C.byref(flag)), "rtk_read_error_flag")
+    if flag.value & 1:
+        raise IndexError("index out of range in self (subject_idx / relation_idx)")
+
+
+def _strict_check(dev, ws, sp):
+    if INDEX_CHECK == "strict" and not torch.cuda.is_current_stream_capturing():
+        _check_now(ws, sp)
 
 
 def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def relation_tables(core, R):
+    """``tables[u] = G x_0 R[u]`` for ALL relations -> ``(n_rel, b, c)`` fp32: the part of stage 1 that only
+    depends on the parameters (einsum of asymmetric/R_TuckER.py:45 applied to every relation row).  Pass the
+    result as ``tables=`` to ``score_1vN`` / ``query_vectors`` while the parameters stay unchanged."""
+    lib = _lib.load()
+    _require_gpu("core", core)
+    if core.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"core must be float32 or bfloat16, got {core.dtype}")
+    bf16 = core.dtype == torch.bfloat16
+    core, R = _operand("core", core.detach(), core.dtype), _operand("R", R.detach(), core.dtype)
+    if core.dim() != 3 or R.dim() != 2 or R.shape[1] != core.shape[0]:
+        raise RuntimeError("expected core (a,b,c), R (nR,a)")
+    a, b, c = core.shape
+    if b != c:
+        raise RuntimeError(f"subject rank {b} must equal object rank {c} (asymmetric/R_TuckER.py:46)")
+    dev = core.device
+    n_rel = R.shape[0]
+    tables = torch.empty((n_rel, b, c), dtype=torch.float32, device=dev)
+    dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
+    with torch.cuda.device(dev):
+        sp = _stream_ptr(dev)
+        scratch = torch.empty(lib.rtk_relation_tables_workspace_bytes(dcode, n_rel, a, b, c), dtype=torch.uint8, device=dev)
+        fn = lib.rtk_relation_tables_bf16 if bf16 else lib.rtk_relation_tables_f32
+        _lib.check(fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, tables.data_ptr(), scratch.data_ptr(), scratch.numel(), sp),
+                   "rtk_relation_tables")
+    return tables
+
+
 def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, sigmoid_mode=None, out=None,
-             out_dtype=torch.float32, padded=None):
+             out_dtype=torch.float32, padded=None, tables=None):
     lib = _lib.load()
     _require_gpu("core", core)
     if core.dtype not in (torch.float32, torch.bfloat16):
@@ -129,7 +207,14 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
     with torch.cuda.device(dev):
         sp = _stream_ptr(dev)
         dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
-        need = lib.rtk_workspace_bytes(dcode, B, R.shape[0], a, b, c)
+        if tables is not None:
+            if (tables.dtype != torch.float32 or tables.device != dev or tuple(tables.shape) != (R.shape[0], b, c)
+                    or not tables.is_contiguous()):
+                raise RuntimeError(f"tables must be a contiguous float32 ({R.shape[0]}, {b}, {c}) tensor on {dev} "
+                                   "(ops.relation_tables)")
+            need = lib.rtk_from_tables_workspace_bytes(B, R.shape[0])
+        else:
+            need = lib.rtk_workspace_bytes(dcode, B, R.shape[0], a, b, c)
         ws = _workspace(dev, sp, need)
         if bf16 and (exact or c > 512):
             raise RuntimeError("bf16 operands: only the bf16 MFMA score kernel exists (c <= 512, exact=False)")
@@ -145,9 +230,26 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
             if mode != "fast":
                 raise RuntimeError("bfloat16 scores use the fast logistic (sigmoid_mode='fast')")
             flags |= _lib.RTK_SCORE_OUT_BF16
-        sflags = flags & (_lib.RTK_SCORE_SIGMOID | _lib.RTK_SCORE_SIGMOID_FAST)
+        sflags = flags & (_lib.RTK_SCORE_SIGMOID | _lib.RTK_SCORE_SIGMOID_FAST | _lib.RTK_SCORE_OUT_BF16)
         v = None
-        if want_v:
+        if tables is not None:
+            # stage 1 against the prebuilt relation tables, then the score kernel on the packed planes
+            if exact or (not bf16 and c > 512):
+                v = torch.empty((B, c), dtype=torch.float32, device=dev)
+                qp = None
+            else:
+                v = torch.empty((B, c), dtype=torch.float32, device=dev) if want_v else None
+                qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev)
+            ft = lib.rtk_query_vectors_from_tables_bf16 if bf16 else lib.rtk_query_vectors_from_tables_f32
+            _lib.check(ft(tables.data_ptr(), R.shape[0], b, c, S.data_ptr(), S.shape[0], r.data_ptr(), h.data_ptr(), B,
+                          v.data_ptr() if v is not None else None, qp.data_ptr() if qp is not None else None,
+                          ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_from_tables")
+            if qp is not None:
+                _lib.check(sp_fn(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld, sflags, sp), "rtk_score_packed")
+            else:
+                _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
+                                             flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
+        elif want_v:
             # two-call form so the fp32 query vectors are kept for backward
             v = torch.empty((B, c), dtype=torch.float32, device=dev)
             use_packed = bf16 or (not exact and c <= 512)
@@ -160,7 +262,7 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
                                                  ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors")
             if use_packed:
                 _lib.check(sp_fn(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
-                                                    sflags, sp), "rtk_score_packed_f32")
+                                 sflags & ~_lib.RTK_SCORE_OUT_BF16, sp), "rtk_score_packed_f32")
             else:
                 _lib.check(lib.rtk_score_f32(v.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), ld,
                                              flags & _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
@@ -169,6 +271,7 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
                                              S.data_ptr(), S.shape[0], O.data_ptr(), N,
                                              r.data_ptr(), h.data_ptr(), B, out.data_ptr(), ld, flags,
                                              ws.data_ptr(), ws.numel(), sp), "rtk_score_1vN_f32")
+        _strict_check(dev, ws, sp)
     return out, v
 
 
@@ -208,36 +311,48 @@ class _Score1vN(torch.autograd.Function):
         return _grads_from_dZ(core, R, S, O, h, r, v, dZ, ctx.needs_input_grad, pdt) + (None,) * 5
 
 
+def _splits_for(M, N, K):
+    """Split-K factor of the dv product: enough 128x128 tiles x chunks to fill 256 CUs twice, chunks >= 512 deep."""
+    tiles = -(-M // 128) * -(-N // 128)
+    return int(max(1, min(64, 512 // max(tiles, 1), K // 512)))
+
+
 def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt):
-    """(g_core, g_R, g_S, g_O) from dZ = d loss / d logits (B, N) fp32 and the saved fp32 query
-    vectors: the two B x N-sized products are HIP GEMMs, the small trilinear remainder torch ops."""
+    """(g_core, g_R, g_S, g_O) from dZ = d loss / d logits (B, N) fp32 and the saved fp32 query vectors,
+    all in HIP kernels with a fixed summation order (bit-identical from run to run): dO = dZ^T v and
+    dv = dZ O on the fp32 MFMA GEMM (split-K slabs added in chunk order), then the stage-1 backward
+    ``rtk_query_vectors_bwd_f32`` (two more GEMMs and a deterministic row scatter)."""
     lib = _lib.load()
     dev = dZ.device
     B, N = dZ.shape
     ldz = dZ.stride(0) if B > 1 else N      # dZ may be the (B, N) view of a padded buffer (bce_loss_1vN)
-    c = O.shape[1]
+    a, b, c = core.shape
+    core, R, S, Of = core.contiguous(), R.contiguous(), S.contiguous(), O.contiguous()
+    gO = gcore = gR = gS = None
     with torch.cuda.device(dev):
         sp = _stream_ptr(dev)
-        gO = None
         if needs[3]:
             # gO[j, k] = sum_d dZ[d, j] * v[d, k]   -- fp32 MFMA GEMM, both operands M-major
             gO = torch.empty((N, c), dtype=torch.float32, device=dev)
             _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, ldz, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
                        "rtk_gemm_f32 (dO)")
-        # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K with float atomics
-        Of = O.contiguous()
-        dv = torch.empty((B, c), dtype=torch.float32, device=dev)
-        splits = max(1, min(256, N // 512))
-        _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, ldz, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
-                                           splits, sp), "rtk_gemm_f32_splitk (dv)")
-    Rb, Sb = R[r], S[h]
-    W = torch.einsum("abc,dc->dab", core, dv)                            # (B, a, b)
-    gcore = torch.einsum("da,db,dc->abc", Rb, Sb, dv) if needs[0] else None
-    gR = gS = None
-    if needs[1]:
-        gR = torch.zeros_like(R).index_add_(0, r, torch.einsum("dab,db->da", W, Sb))
-    if needs[2]:
-        gS = torch.zeros_like(S).index_add_(0, h, torch.einsum("dab,da->db", W, Rb))
+        if needs[0] or needs[1] or needs[2]:
+            # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K, slabs reduced in chunk order
+            dv = torch.empty((B, c), dtype=torch.float32, device=dev)
+            splits = _splits_for(B, c, N)
+            skw = torch.empty(max(256, lib.rtk_gemm_f32_splitk_workspace_bytes(B, c, splits)), dtype=torch.uint8, device=dev)
+            _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, ldz, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
+                                               splits, skw.data_ptr(), skw.numel(), sp), "rtk_gemm_f32_splitk (dv)")
+            gcore = torch.empty_like(core) if needs[0] else None
+            gR = torch.empty_like(R) if needs[1] else None
+            gS = torch.empty_like(S) if needs[2] else None
+            bws = torch.empty(lib.rtk_query_bwd_workspace_bytes(B, a, b, c), dtype=torch.uint8, device=dev)
+            _lib.check(lib.rtk_query_vectors_bwd_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0], S.data_ptr(),
+                                                     S.shape[0], r.data_ptr(), h.data_ptr(), B, dv.data_ptr(),
+                                                     gcore.data_ptr() if needs[0] else None,
+                                                     gR.data_ptr() if needs[1] else None,
+                                                     gS.data_ptr() if needs[2] else None,
+                                                     bws.data_ptr(), bws.numel(), sp), "rtk_query_vectors_bwd_f32")
     if pdt != torch.float32:
         gcore, gR, gS, gO = [g.to(pdt) if g is not None else None for g in (gcore, gR, gS, gO)]
     # symmetric model: S and O are the same tensor passed twice; autograd sums gS + gO
@@ -299,7 +414,7 @@ def bce_loss_1vN(core, R, S, O, subject_idx, relation_idx, flt, item_ids, label_
 
 
 def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=False, sigmoid_mode=None,
-              out_dtype=torch.float32):
+              out_dtype=torch.float32, tables=None):
     """``sigmoid((G x_0 R[r] x_1 S[h]) . O^T)`` for a batch of (h, r) queries -> ``(B, N)``.
 
     Same operands and result as the body of the reference's ``score_fn``
@@ -309,6 +424,8 @@ def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=Fals
     ``out_dtype=torch.bfloat16`` (bf16 operands, no autograd): the scores are rounded to bf16 in the
     kernel -- the dtype the reference's bf16 model returns -- which halves the dominant HBM traffic;
     bit-identical to ``score_1vN(...).to(torch.bfloat16)``.
+    ``tables`` (no autograd): the prebuilt relation tables of these parameters (``relation_tables(core, R)``);
+    stage 1 then only does the subject-mode contraction -- same bits as without them.
     """
     needs_grad = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (core, R, S, O))
@@ -317,51 +434,109 @@ def score_1vN(core, R, S, O, subject_idx, relation_idx, sigmoid=True, exact=Fals
             raise RuntimeError("bfloat16 scores are an inference option (no autograd)")
         return _Score1vN.apply(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, sigmoid_mode)
     out, _ = _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False, sigmoid_mode=sigmoid_mode,
-                      out_dtype=out_dtype)
+                      out_dtype=out_dtype, tables=tables)
     return out
 
 
-def score_1vN_into(core, R, S, O, subject_idx, relation_idx, out, sigmoid=True, exact=False, sigmoid_mode=None):
-    """``score_1vN`` writing into a caller-provided (B, N) buffer (row stride >= N); no autograd.
-    Used by the entity-sharded scorer so the local block lands in its all-gather slot."""
+def score_1vN_into(core, R, S, O, subject_idx, relation_idx, out, sigmoid=True, exact=False, sigmoid_mode=None,
+                   tables=None):
+    """``score_1vN`` writing into a caller-provided (B, N) buffer (row stride >= N; float32, or bfloat16
+    for bf16 operands with the fast logistic); no autograd.  Used by the entity-sharded scorer so the
+    local block lands in its all-gather slot."""
     with torch.no_grad():
         _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v=False,
-                 sigmoid_mode=sigmoid_mode, out=out)
+                 sigmoid_mode=sigmoid_mode, out=out, out_dtype=out.dtype, tables=tables)
     return out
 
 
-def query_vectors(core, R, S, subject_idx, relation_idx):
-    """Stage 1 only: ``v[d] = S[h_d] . (G x_0 R[r_d])`` -> ``(B, c)`` fp32 (R_TuckER.py:43-46)."""
+def query_vectors(core, R, S, subject_idx, relation_idx, tables=None, packed=False):
+    """Stage 1 only: ``v[d] = S[h_d] . (G x_0 R[r_d])`` -> ``(B, c)`` fp32 (R_TuckER.py:43-46).
+    ``packed=True`` returns ``(v, q_packed)`` with the packed query planes the score kernels consume."""
     lib = _lib.load()
-    core, R, S = _f32c("core", core), _f32c("R", R), _f32c("S", S)
+    _require_gpu("core", core)
+    bf16 = core.dtype == torch.bfloat16
+    dt = core.dtype
+    core, R, S = _operand("core", core, dt), _operand("R", R, dt), _operand("S", S, dt)
     dev = core.device
     a, b, c = core.shape
     h, r = _idx("subject_idx", subject_idx, dev), _idx("relation_idx", relation_idx, dev)
     B = h.numel()
+    dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
     v = torch.empty((B, c), dtype=torch.float32, device=dev)
+    qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev) if packed else None
     with torch.cuda.device(dev):
         sp = _stream_ptr(dev)
-        ws = _workspace(dev, sp, lib.rtk_workspace_bytes(_lib.RTK_F32, B, R.shape[0], a, b, c))
-        _lib.check(lib.rtk_query_vectors_f32(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0], S.data_ptr(),
-                                             S.shape[0], r.data_ptr(), h.data_ptr(), B, v.data_ptr(), None,
-                                             ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_f32")
-    return v
+        if tables is not None:
+            ws = _workspace(dev, sp, lib.rtk_from_tables_workspace_bytes(B, R.shape[0]))
+            ft = lib.rtk_query_vectors_from_tables_bf16 if bf16 else lib.rtk_query_vectors_from_tables_f32
+            _lib.check(ft(tables.data_ptr(), R.shape[0], b, c, S.data_ptr(), S.shape[0], r.data_ptr(), h.data_ptr(), B,
+                          v.data_ptr(), qp.data_ptr() if packed else None, ws.data_ptr(), ws.numel(), sp),
+                       "rtk_query_vectors_from_tables")
+        else:
+            ws = _workspace(dev, sp, lib.rtk_workspace_bytes(dcode, B, R.shape[0], a, b, c))
+            qv = lib.rtk_query_vectors_bf16 if bf16 else lib.rtk_query_vectors_f32
+            _lib.check(qv(core.data_ptr(), a, b, c, R.data_ptr(), R.shape[0], S.data_ptr(),
+                          S.shape[0], r.data_ptr(), h.data_ptr(), B, v.data_ptr(), qp.data_ptr() if packed else None,
+                          ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors")
+        _strict_check(dev, ws, sp)
+    return (v, qp) if packed else v
+
+
+def pack_query_vectors(v, dtype):
+    """Packed query planes (csrc/rtk_pack.h) of fp32 query vectors ``v (B, c)`` for the score kernels of
+    operand type ``dtype`` -- the hand-over when stage 1 ran elsewhere (entity-sharded scoring with
+    stage 1 split over the ranks: every rank contracts its slice of the batch, the B x c vectors are
+    all-gathered, each rank packs them and scores its entity shard)."""
+    lib = _lib.load()
+    _require_gpu("v", v)
+    v = v.contiguous().float()
+    B, c = v.shape
+    bf16 = dtype == torch.bfloat16
+    dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
+    qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=v.device)
+    with torch.cuda.device(v.device):
+        _lib.check(lib.rtk_pack_query_vectors(v.data_ptr(), B, c, dcode, qp.data_ptr(), _stream_ptr(v.device)),
+                   "rtk_pack_query_vectors")
+    return qp
+
+
+def score_packed_into(qp, B, O, out, sigmoid=True, sigmoid_mode=None):
+    """Stage 2 alone: ``out[d, j] = logistic(v_d . O[j])`` from packed query planes into a (B, n_local)
+    buffer (float32, or bfloat16 for bf16 operands)."""
+    lib = _lib.load()
+    _require_gpu("O", O)
+    dev = O.device
+    bf16 = O.dtype == torch.bfloat16
+    O = O.contiguous()
+    N, c = O.shape
+    mode = sigmoid_mode or DEFAULT_SIGMOID
+    flags = (_lib.RTK_SCORE_SIGMOID if sigmoid else 0) | (_lib.RTK_SCORE_SIGMOID_FAST if (sigmoid and mode == "fast") else 0)
+    if out.dtype == torch.bfloat16:
+        if not bf16 or not sigmoid or mode != "fast":
+            raise RuntimeError("bfloat16 scores: bf16 operands and the fast logistic")
+        flags |= _lib.RTK_SCORE_OUT_BF16
+    if tuple(out.shape) != (B, N) or out.stride(1) != 1 or out.device != dev:
+        raise RuntimeError(f"out must be ({B}, {N}) on {dev} with unit column stride")
+    fn = lib.rtk_score_packed_bf16 if bf16 else lib.rtk_score_packed_f32
+    with torch.cuda.device(dev):
+        _lib.check(fn(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), out.stride(0) if B > 1 else N, flags,
+                      _stream_ptr(dev)), "rtk_score_packed")
+    return out
 
 
 def check_device_errors(device=None):
     """Synchronise and raise ``IndexError`` if a kernel saw an out-of-range subject /
     relation id since the last check (the kernels clamp such ids instead of faulting;
-    the reference raises IndexError on CPU / asserts on device)."""
-    lib = _lib.load()
+    the reference raises IndexError on CPU / asserts on device).  Each workspace's word is read and
+    cleared on the stream that owns it."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    bad = False
-    for (di, sp), ws in _workspaces.items():
+    bad = None
+    for (di, sp), ws in list(_workspaces.items()):
         if di != dev.index:
             continue
-        flag = C.c_uint32(0)
-        _lib.check(lib.rtk_read_error_flag(ws.data_ptr(), sp, C.byref(flag)), "rtk_read_error_flag")
-        if flag.value & 1:
-            bad = True
-            ws[:4].zero_()
-    if bad:
-        raise IndexError("index out of range in self (subject_idx / relation_idx)")
+        try:
+            _check_now(ws, sp)
+        except IndexError as e:
+            bad = e
+    if bad is not None:
+        raise bad

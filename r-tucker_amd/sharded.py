@@ -46,11 +46,22 @@ class ShardedEntityScorer:
     """``score(...)`` = the reference's ``score_fn`` with O row-sharded over a process group.
 
     ``local_score(core, R, S, O_loc, h, r, out=...)`` computes the (B, n_loc) block; the
-    default is the HIP path (``ops.score_1vN_into``).  Tests inject a CPU function to
+    default is the HIP path (``ops.score_1vN_into``).  Tests inject CPU functions to
     exercise the sharding / gather logic under the gloo backend.
+
+    Stage 1 (the query vectors) is cheap next to a shard's score block when the relation rank is small
+    (WN18RR: a = 10) and is then simply replicated.  For a large relation rank it is as expensive as the
+    whole score shard (C5: 1.1 TFLOP), so with ``stage1="split"`` (the ``"auto"`` choice
+    for a > 32) every rank contracts only its ``ceil(B / P)`` slice of the batch, the ``(B, c)`` fp32
+    vectors are exchanged with one small all-gather (16 MB at C5) and each rank packs them for its score
+    kernel.  The rows are computed by the same kernels either way: bit-identical scores.
+
+    ``score_dtype=torch.bfloat16`` (bf16 operands): the local kernel writes bf16 scores, which halves the
+    score exchange.
     """
 
-    def __init__(self, n_ent: int, group=None, local_score=None):
+    def __init__(self, n_ent: int, group=None, local_score=None, stage1="auto", score_dtype=torch.float32,
+                 query_vectors_fn=None, score_from_v_fn=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -59,15 +70,23 @@ class ShardedEntityScorer:
             from .ops import score_1vN_into
             local_score = score_1vN_into
         self.local_score = local_score
+        if stage1 not in ("auto", "replicated", "split"):
+            raise ValueError("stage1 must be auto | replicated | split")
+        self.stage1 = stage1
+        self.score_dtype = score_dtype
+        self.query_vectors_fn = query_vectors_fn
+        self.score_from_v_fn = score_from_v_fn
         self._gathered = None
+        self._v_all = None
 
     def local_block(self, full_entity_matrix: torch.Tensor) -> torch.Tensor:
         return self.shards.take(full_entity_matrix, self.rank)
 
     def _buffer(self, B, device, dtype):
-        # rows start on ROW_ALIGN-element boundaries (ops.alloc_scores): the storage is (P, B, pitch)
+        # rows start on 128-byte boundaries (ops.alloc_scores): the storage is (P, B, pitch)
         from .ops import ROW_ALIGN
-        pitch = -(-self.shards.n_loc // ROW_ALIGN) * ROW_ALIGN
+        unit = ROW_ALIGN * (4 // torch.empty((), dtype=dtype).element_size()) if ROW_ALIGN > 1 else 1
+        pitch = -(-self.shards.n_loc // unit) * unit
         need = (self.world, B, pitch)
         g = self._gathered
         if g is None or tuple(g.shape) != need or g.device != device or g.dtype != dtype:
@@ -75,14 +94,52 @@ class ShardedEntityScorer:
             self._gathered = g
         return g
 
-    def score_gathered(self, core, R, S, O_loc, subject_idx, relation_idx, **kw) -> torch.Tensor:
+    def _split_stage1(self, core) -> bool:
+        if self.world == 1 or self.stage1 == "replicated":
+            return False
+        return self.stage1 == "split" or core.shape[0] > 32
+
+    def query_vectors_split(self, core, R, S, subject_idx, relation_idx, **kw) -> torch.Tensor:
+        """``(B, c)`` fp32 query vectors with the batch split over the ranks: this rank contracts queries
+        ``[rank * B_loc, (rank + 1) * B_loc)``, one all-gather of ``B_loc x c`` floats assembles the rest."""
+        B = int(subject_idx.numel())
+        c = core.shape[2]
+        B_loc = -(-B // self.world)
+        lo, hi = min(self.rank * B_loc, B), min((self.rank + 1) * B_loc, B)
+        va = self._v_all
+        if va is None or tuple(va.shape) != (self.world * B_loc, c) or va.device != core.device:
+            va = self._v_all = torch.zeros((self.world * B_loc, c), dtype=torch.float32, device=core.device)
+        fn = self.query_vectors_fn
+        if fn is None:
+            from .ops import query_vectors as fn
+        mine = va[self.rank * B_loc:(self.rank + 1) * B_loc]
+        if hi > lo:
+            mine[: hi - lo].copy_(fn(core, R, S, subject_idx.view(-1)[lo:hi], relation_idx.view(-1)[lo:hi], **kw))
+        dist.all_gather_into_tensor(va.view(-1), mine.reshape(-1), group=self.group)
+        return va[:B]
+
+    def _score_local(self, core, R, S, O_loc, subject_idx, relation_idx, mine, tables=None, **kw):
+        if not self._split_stage1(core):
+            if tables is not None:
+                kw = dict(kw, tables=tables)
+            self.local_score(core, R, S, O_loc, subject_idx, relation_idx, out=mine, **kw)
+            return
+        qkw = {"tables": tables} if tables is not None else {}
+        v = self.query_vectors_split(core, R, S, subject_idx, relation_idx, **qkw)
+        if self.score_from_v_fn is not None:
+            self.score_from_v_fn(v, O_loc, out=mine, **kw)
+        else:
+            from .ops import pack_query_vectors, score_packed_into
+            score_packed_into(pack_query_vectors(v, O_loc.dtype), v.shape[0], O_loc, mine, **kw)
+
+    def score_gathered(self, core, R, S, O_loc, subject_idx, relation_idx, tables=None, **kw) -> torch.Tensor:
         """All ranks' score blocks, ``(P, B, n_loc)``; slot p = rank p's entities.
         Columns past the real entity count in the last shard are padding (sigmoid(0) = 0.5)."""
         B = int(subject_idx.numel())
-        g = self._buffer(B, core.device, torch.float32)      # the score kernels write fp32 for either operand type
+        g = self._buffer(B, core.device, self.score_dtype)
         n_loc = self.shards.n_loc
         mine = g[self.rank][:, :n_loc]                        # (B, n_loc) view: the kernel writes in place
-        self.local_score(core, R, S, O_loc, subject_idx, relation_idx, out=mine, **kw)
+        self._score_local(core, R, S, O_loc, subject_idx, relation_idx, mine, tables=tables, **kw)
         if self.world > 1:
             # in-place all-gather of the padded storage: input is the rank-th slice of the output buffer
             dist.all_gather_into_tensor(g.view(-1), g[self.rank].view(-1), group=self.group)
@@ -118,9 +175,9 @@ class ShardedEntityScorer:
         B = int(subject_idx.numel())
         n_loc, lo = self.shards.n_loc, self.rank * self.shards.n_loc
         n_valid = max(0, min(n_loc, self.shards.n_ent - lo))      # the last shard's padding rows are not entities
-        g = self._buffer(B, core.device, torch.float32)
+        g = self._buffer(B, core.device, torch.float32)      # the ranking kernels read fp32 scores
         mine = g[self.rank][:, :n_loc]
-        self.local_score(core, R, S, O_loc, subject_idx, relation_idx, out=mine, **kw)
+        self._score_local(core, R, S, O_loc, subject_idx, relation_idx, mine, **kw)
         block = mine[:, :n_valid] if n_valid > 0 else None
         pt = (target_scores_fn(block, object_idx, lo) if block is not None
               else torch.full((B,), float("-inf"), dtype=torch.float32, device=core.device))

@@ -1,19 +1,57 @@
-"""Container types the scoring closure reads (``T.core``, ``T.factors`` /
-``T.regular_factors``, ``T.shared_factor``).
+"""Tucker / shared-factor Tucker containers (the subset of ``tucker_riemopt.Tucker`` /
+``tucker_riemopt.SFTucker`` the reference touches; that package is pinned at 1.0.1 in the reference's
+``poetry.lock`` but is neither vendored nor installable offline, so this is our own implementation of
+the textbook operations -- SURVEY.md Appendix C; parity with the package is UNPINNED, the algebra is
+validated by identities in ``tests/test_riemannian.py``).
 
-They take the constructor signatures the reference uses for
-``tucker_riemopt.Tucker`` / ``tucker_riemopt.SFTucker`` (``train.py:39,41``) so that
-``extract_tensor`` can build them unchanged; on the scoring path they are plain
-attribute holders, exactly what ``score_fn`` needs
-(``src/model/asymmetric/R_TuckER.py:43-47``, ``src/model/symmetric/R_TuckER.py:40-44``).
-The Riemannian machinery of ``tucker_riemopt`` (round / project / grad) is outside
-this package's scope.
+On the scoring path they are attribute holders: ``score_fn`` reads ``T.core``, ``T.factors`` /
+``T.regular_factors``, ``T.shared_factor`` (``src/model/asymmetric/R_TuckER.py:43-47``,
+``src/model/symmetric/R_TuckER.py:40-44``); constructor signatures are the ones ``extract_tensor``
+uses (``train.py:39,41``).  Beyond that:
+
+* ``norm()``  -- Frobenius norm of the represented tensor, differentiable (``train.py:79``:
+  ``regularization_coeff * T.norm() ** 2`` inside the differentiated ``loss_fn``), computed through the
+  factor Gram matrices (cost O(sum n_i r_i^2), never the dense tensor);
+* ``round(rank)`` -- retraction by truncated HOSVD: thin QR of every factor, the R factors absorbed
+  into the core, truncated SVD of every core unfolding (``asymmetric/optim.py:108``,
+  ``symmetric/optim.py:102``); for the shared-factor tensor the shared modes get ONE common factor;
+* ``full()`` -- the dense tensor (tests, tiny sizes only).
+
+Everything is plain torch on whatever device the operands live on (QR / SVD of small matrices: the
+reference does the same through tucker_riemopt's torch backend); the scoring arithmetic is NOT here.
 """
 from __future__ import annotations
 
 from typing import Sequence
 
 import torch
+
+
+def _mode_dot(core: torch.Tensor, mat: torch.Tensor, mode: int) -> torch.Tensor:
+    """core x_mode mat, mat of shape (new, old): contracts axis ``mode`` of the core with mat's columns."""
+    return torch.movedim(torch.tensordot(mat, core, dims=([1], [mode])), 0, mode)
+
+
+def _unfold(core: torch.Tensor, mode: int) -> torch.Tensor:
+    return torch.movedim(core, mode, 0).reshape(core.shape[mode], -1)
+
+
+def _gram_norm(core: torch.Tensor, grams: Sequence[torch.Tensor]) -> torch.Tensor:
+    """||core x_0 U_0 x_1 U_1 x_2 U_2||_F from the Gram matrices U_i^T U_i:  <core x_i gram_i, core>^(1/2)."""
+    t = core
+    for i, g in enumerate(grams):
+        t = _mode_dot(t, g, i)
+    return torch.sqrt(torch.clamp((t * core).sum(), min=0.0))
+
+
+def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
+    """The r leading left singular vectors of ``mat`` (columns), via the small Gram eigenproblem when the
+    matrix is wide (unfoldings are r x r^2)."""
+    if mat.shape[0] <= r:
+        r = mat.shape[0]
+    # SVD of the (small) matrix itself: accuracy matters more than speed here (2r x 4r^2 at most)
+    U, _, _ = torch.linalg.svd(mat, full_matrices=False)
+    return U[:, :r]
 
 
 class Tucker:
@@ -28,9 +66,50 @@ class Tucker:
     def rank(self):
         return tuple(self.core.shape)
 
+    @property
+    def shape(self):
+        return tuple(f.shape[0] for f in self.factors)
+
+    def norm(self) -> torch.Tensor:
+        return _gram_norm(self.core, [f.transpose(0, 1) @ f for f in self.factors])
+
+    def full(self) -> torch.Tensor:
+        t = self.core
+        for i, f in enumerate(self.factors):
+            t = _mode_dot(t, f, i)
+        return t
+
+    def round(self, rank: Sequence[int]) -> "Tucker":
+        """Best-effort rank-``rank`` approximation with orthonormal factors (truncated HOSVD)."""
+        core = self.core
+        qs = []
+        for i, f in enumerate(self.factors):
+            q, r = torch.linalg.qr(f)                      # thin: (n, k), (k, k)
+            qs.append(q)
+            core = _mode_dot(core, r, i)
+        new_factors = []
+        for i, q in enumerate(qs):
+            u = _truncated_left_basis(_unfold(core, i), int(rank[i]))
+            new_factors.append(q @ u)
+            core = _mode_dot(core, u.transpose(0, 1), i)
+        return Tucker(core, new_factors)
+
+    def __add__(self, other: "Tucker") -> "Tucker":
+        """Block-diagonal sum (ranks add)."""
+        a0, b0, c0 = self.core.shape
+        a1, b1, c1 = other.core.shape
+        core = self.core.new_zeros((a0 + a1, b0 + b1, c0 + c1))
+        core[:a0, :b0, :c0] = self.core
+        core[a0:, b0:, c0:] = other.core
+        return Tucker(core, [torch.cat([f, g], dim=1) for f, g in zip(self.factors, other.factors)])
+
+    def __rmul__(self, scalar) -> "Tucker":
+        return Tucker(scalar * self.core, list(self.factors))
+
 
 class SFTucker:
-    """Shared-factor Tucker: the last ``num_shared_factors`` modes use ``shared_factor``."""
+    """Shared-factor Tucker: the last ``num_shared_factors`` modes use ``shared_factor``
+    (``X = core x_0 R x_1 E x_2 E`` for the symmetric model)."""
 
     def __init__(self, core: torch.Tensor, regular_factors: Sequence[torch.Tensor],
                  num_shared_factors: int, shared_factor: torch.Tensor):
@@ -42,3 +121,47 @@ class SFTucker:
     @property
     def rank(self):
         return tuple(self.core.shape)
+
+    @property
+    def factors(self):
+        """All mode factors in core-axis order (the shared one repeated)."""
+        return self.regular_factors + [self.shared_factor] * self.num_shared_factors
+
+    def norm(self) -> torch.Tensor:
+        ge = self.shared_factor.transpose(0, 1) @ self.shared_factor
+        grams = [f.transpose(0, 1) @ f for f in self.regular_factors] + [ge] * self.num_shared_factors
+        return _gram_norm(self.core, grams)
+
+    def full(self) -> torch.Tensor:
+        t = self.core
+        for i, f in enumerate(self.factors):
+            t = _mode_dot(t, f, i)
+        return t
+
+    def round(self, rank: Sequence[int]) -> "SFTucker":
+        """Truncated HOSVD with ONE basis for the shared modes: the leading left singular vectors of the
+        concatenated shared-mode unfoldings (the subspace that serves both modes best in the least-squares
+        sense)."""
+        nreg = len(self.regular_factors)
+        core = self.core
+        qs = []
+        for i, f in enumerate(self.regular_factors):
+            q, r = torch.linalg.qr(f)
+            qs.append(q)
+            core = _mode_dot(core, r, i)
+        qe, re = torch.linalg.qr(self.shared_factor)
+        for m in range(nreg, nreg + self.num_shared_factors):
+            core = _mode_dot(core, re, m)
+        new_regular = []
+        for i, q in enumerate(qs):
+            u = _truncated_left_basis(_unfold(core, i), int(rank[i]))
+            new_regular.append(q @ u)
+            core = _mode_dot(core, u.transpose(0, 1), i)
+        cat = torch.cat([_unfold(core, m) for m in range(nreg, nreg + self.num_shared_factors)], dim=1)
+        ue = _truncated_left_basis(cat, int(rank[nreg]))
+        for m in range(nreg, nreg + self.num_shared_factors):
+            core = _mode_dot(core, ue.transpose(0, 1), m)
+        return SFTucker(core, new_regular, self.num_shared_factors, qe @ ue)
+
+    def __rmul__(self, scalar) -> "SFTucker":
+        return SFTucker(scalar * self.core, list(self.regular_factors), self.num_shared_factors, self.shared_factor)

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_size_queries(lib):
-    assert lib.rtk_version() >= 100
+    assert lib.rtk_version() >= 200
     # C2 shapes: tables 22*200*200*4 + v 512*200*4 + packed planes + headers
     need = lib.rtk_workspace_bytes(0, 512, 22, 10, 200, 200)
     assert 22 * 200 * 200 * 4 + 512 * 200 * 4 <= need <= 8 << 20

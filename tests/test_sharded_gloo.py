@@ -49,6 +49,58 @@ def _worker(rank, world, port, n_ent, n_rel, B, rank3, q):
         dist.destroy_process_group()
 
 
+def _split_worker(rank, world, port, n_ent, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from r_tucker_amd.sharded import ShardedEntityScorer
+        n_rel, rank3 = 5, (3, 8, 8)
+        core, R, S, O = [torch.from_numpy(x) for x in gen.make_params(n_ent, n_rel, rank3, 11)]
+        h, r = [torch.from_numpy(x) for x in gen.make_queries(n_ent, n_rel, B, 11)]
+        calls = []
+
+        def qv(core_, R_, S_, hh, rr, **kw):          # stage 1 of a SLICE of the batch
+            calls.append(int(hh.numel()))
+            return orc.query_vectors_ref(core_, R_, S_, hh, rr)
+
+        def score_from_v(v, O_loc, out, **kw):        # stage 2 on the gathered vectors
+            out.copy_(torch.sigmoid(v @ O_loc.T))
+
+        sc = ShardedEntityScorer(n_ent, local_score=_oracle_local, stage1="split", query_vectors_fn=qv,
+                                 score_from_v_fn=score_from_v)
+        P = sc.score(core, R, S, sc.local_block(O), h, r)
+        ref = orc.score_ref(core, R, S, O, h, r)
+        B_loc = -(-B // world)
+        want = max(0, min(B, (rank + 1) * B_loc) - min(B, rank * B_loc))
+        ok = torch.allclose(P, ref, atol=1e-6) and calls == ([want] if want else [])
+        # the "auto" choice: small relation rank -> replicated (no query-vector exchange)
+        sc2 = ShardedEntityScorer(n_ent, local_score=_oracle_local, stage1="auto", query_vectors_fn=qv,
+                                  score_from_v_fn=score_from_v)
+        n_before = len(calls)
+        P2 = sc2.score(core, R, S, sc2.local_block(O), h, r)
+        ok = ok and torch.allclose(P2, ref, atol=1e-6) and len(calls) == n_before
+        q.put((rank, bool(ok), float((P - ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ent,B", [(64, 9), (101, 2), (37, 1)])   # ragged batch slices, an empty slice, ragged shards
+def test_sharded_stage1_split_world2_gloo(n_ent, B):
+    """Stage 1 split over the ranks (each contracts ceil(B/P) queries, one all-gather of the B x c vectors),
+    stage 2 on the local entity shard, scores all-gathered: same matrix as the oracle on one device."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(rk, 2, port, n_ent, B, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert [r[1] for r in res] == [True, True], res
+
+
 class _Flt:
     """The three arrays of evaluation.DeviceFilter, on the CPU."""
     def __init__(self, slot_of_item, pair_ptr, pair_obj):

@@ -18,7 +18,7 @@ import r_tucker_amd as rt  # noqa: E402
 from r_tucker_amd.data import Data, KG_dataset  # noqa: E402
 
 
-def train(epochs=30, rank=(10, 200, 200), batch=512, lr=3e-3, seed=322, smoothing=0.1, log=print):
+def train(epochs=30, rank=(10, 200, 200), batch=512, lr=3e-3, seed=322, smoothing=0.1, log=print, lr_decay=1.0):
     torch.manual_seed(seed)
     np.random.seed(seed)
     data = Data(os.path.join(ROOT, "data", "WN18RR") + "/", reverse=True)
@@ -30,6 +30,7 @@ def train(epochs=30, rank=(10, 200, 200), batch=512, lr=3e-3, seed=322, smoothin
         for p in model.parameters():
             p.copy_(torch.randn_like(p) * (0.3 if p.dim() == 3 else 0.1))
     opt = torch.optim.Adam(model.parameters(), lr=lr)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=lr_decay)     # per epoch; 1.0 = constant
     flt = rt.DeviceFilter(train_set, "cuda")
     n = len(train_set)
     t0 = time.perf_counter()
@@ -45,6 +46,7 @@ def train(epochs=30, rank=(10, 200, 200), batch=512, lr=3e-3, seed=322, smoothin
             loss.backward()
             opt.step()
             tot += float(loss.detach()) if (lo // batch) % 50 == 0 else 0.0
+        sched.step()
         if ep % 5 == 4 or ep == epochs - 1:
             m, l = rt.evaluate(model, test_set, batch_size=batch)
             torch.cuda.synchronize()
@@ -56,5 +58,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=30)
     ap.add_argument("--lr", type=float, default=3e-3)
+    ap.add_argument("--lr-decay", type=float, default=1.0)
     a = ap.parse_args()
-    train(a.epochs, lr=a.lr)
+    train(a.epochs, lr=a.lr, lr_decay=a.lr_decay)
