@@ -14,5 +14,6 @@ from . import _lib  # noqa: F401
 from .evaluation import DeviceFilter, evaluate, filtered_ranks, metrics_from_ranks  # noqa: F401
 from .model.asymmetric import R_TuckER as AsymmetricR_TuckER  # noqa: F401
 from .model.symmetric import R_TuckER as SymmetricR_TuckER  # noqa: F401
+from .riemannian import TuckerRiemannian, SFTuckerRiemannian, set_backend  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,156 @@
+"""Training / evaluation driver with the reference's surface (``train.py:20-167``): ``define_optimizer``,
+``extract_tensor``, ``train_one_epoch``, ``evaluate``, ``train`` with the same arguments and return values
+(loss / grad-norm averages, metric dictionaries ``{"mrr", "hits@1", "hits@3", "hits@10"}``, a ``StateDict``),
+built MI355X-first on this package's pieces:
+
+* no ``DataLoader`` and no dense ``(B, n_ent)`` target matrix: the ``(subject, relation) -> objects`` lists of a
+  split live on the GPU once as a CSR (``evaluation.DeviceFilter``) and a batch is an index tensor; the loss
+  term ``BCELoss(score_fn(T), targets)`` of ``train.py:79`` is ``ops.bce_loss_1vN`` (scores, label-smoothed BCE
+  and d loss / d logits in HIP kernels; ``targets = (1 - eps) * multi_hot + eps / N`` as ``Dataset.py:51-52``);
+* ``loss_fn(T) = BCE + regularization_coeff * T.norm() ** 2`` is differentiated by the Riemannian optimizer at
+  the doubled-rank construct exactly as the reference's is (``optim.fit(loss_fn, x_k)``, then ``optim.step()``);
+* evaluation is ``evaluation.evaluate``: HIP scores + on-device filtered ranking, relation tables cached.
+
+The shuffle uses ``torch.randperm`` on the device with ``drop_last`` semantics (``train.py:227-228``).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from .evaluation import DeviceFilter, evaluate as _evaluate
+from .tucker import SFTucker, Tucker
+from .utils.storage import Losses, Metrics, StateDict
+from .utils.utils import Timer
+
+
+def _is_symmetric(model) -> bool:
+    return hasattr(model, "E")
+
+
+def define_optimizer(model, cfg, mode: str, opt: str):
+    """``train.py:20-34``: the Riemannian optimizer over ``[core, S, R, O]`` (asymmetric) / ``[core, E, R]``."""
+    if mode == "symmetric":
+        from .model.symmetric.optim import RGD, RSGDwithMomentum, RiemannianAdam
+        param_list = nn.ParameterList([model.core, model.E.weight, model.R.weight])
+    else:
+        from .model.asymmetric.optim import RGD, RSGDwithMomentum, RiemannianAdam
+        param_list = nn.ParameterList([model.core, model.S.weight, model.R.weight, model.O.weight])
+    rank, lr = cfg.model_cfg.manifold_rank, cfg.train_cfg.learning_rate
+    if opt == "rsgd":
+        return RSGDwithMomentum(param_list, rank, lr, cfg.train_cfg.momentum_beta)
+    if opt == "rgd":
+        return RGD(param_list, rank, lr)
+    if opt == "adam":
+        return RiemannianAdam(param_list, rank, lr, step_velocity=1)
+    raise NotImplementedError("Such optimization method is not implemented")
+
+
+def extract_tensor(model):
+    """``train.py:37-42``: the live parameters as a Tucker / SFTucker (no copy)."""
+    if _is_symmetric(model):
+        return SFTucker(model.core.data, [model.R.weight], num_shared_factors=2, shared_factor=model.E.weight)
+    return Tucker(model.core.data, [model.R.weight, model.S.weight, model.O.weight])
+
+
+def batch_loss_fn(model, subject_idx, relation_idx, flt, item_ids, label_smoothing, regularization_coeff):
+    """``loss_fn`` of ``train.py:79`` for one batch, as a function of the container ``T``."""
+    sym = _is_symmetric(model)
+
+    def loss_fn(T):
+        if sym:
+            core, R, S, O = T.core, T.regular_factors[0], T.shared_factor, T.shared_factor
+        else:
+            core, (R, S, O) = T.core, T.factors
+        bce = ops.bce_loss_1vN(core, R, S, O, subject_idx, relation_idx, flt, item_ids, label_smoothing=label_smoothing)
+        return bce + regularization_coeff * T.norm() ** 2
+
+    return loss_fn
+
+
+def train_one_epoch(model, optimizer, train_flt: DeviceFilter, batch_size, label_smoothing, regularization_coeff=1e-4,
+                    max_batches=None, log=None):
+    """``train.py:69-91``: one pass over the (s, r) pairs of the train split; returns the mean loss and mean
+    Riemannian gradient norm over the batches."""
+    model.train()
+    dev = train_flt.device
+    n = train_flt.features.shape[0]
+    n_batches = n // batch_size                         # drop_last=True
+    if max_batches is not None:
+        n_batches = min(n_batches, max_batches)
+    perm = torch.randperm(n, device=dev)
+    train_loss = torch.zeros((), device=dev)
+    train_grad_norm = torch.zeros((), device=dev)
+    with ops.index_check("deferred"):                   # ids come from the dataset's own vocabulary: one check per epoch
+        for b in range(n_batches):
+            ids = perm[b * batch_size:(b + 1) * batch_size]
+            f = train_flt.features[ids]
+            loss_fn = batch_loss_fn(model, f[:, 0].contiguous(), f[:, 1].contiguous(), train_flt, ids, label_smoothing,
+                                    regularization_coeff)
+            x_k = extract_tensor(model)
+            grad_norm = optimizer.fit(loss_fn, x_k)
+            optimizer.step()
+            train_grad_norm += grad_norm.detach()
+            train_loss += optimizer.loss.detach()
+            optimizer.zero_grad(set_to_none=True)
+            if log is not None and (b + 1) % 50 == 0:
+                log(f"  batch {b + 1}/{n_batches}: loss {train_loss.item() / (b + 1):.6f}  grad norm {train_grad_norm.item() / (b + 1):.4e}")
+    ops.check_device_errors(dev)
+    denom = max(n_batches, 1)
+    return train_loss.item() / denom, train_grad_norm.item() / denom
+
+
+def evaluate(model, dataset, batch_size=512, flt: DeviceFilter = None):
+    """``train.py:94-125``: ``(metrics dict averaged over the queries, mean BCE loss)``."""
+    return _evaluate(model, dataset, batch_size=batch_size, flt=flt)
+
+
+def train(model, optimizer, train_set, val_set, test_set, config, regulizer, scheduler=None, log=print, wandb_run=None,
+          max_batches_per_epoch=None) -> StateDict:
+    """``train.py:128-167``: the epoch loop with per-epoch validation / test evaluation, histories, checkpoints
+    (``snapshot`` every epoch, ``rk_<rank>_<epoch>`` when the validation MRR improves by more than 5e-4)."""
+    dev = next(model.parameters()).device
+    timer = Timer()
+    losses = Losses() if not config.state_dict else config.state_dict.losses
+    metrics = Metrics() if not config.state_dict else config.state_dict.metrics
+    tc = config.train_cfg
+    start_epoch = 1 if not config.state_dict else config.state_dict.last_epoch
+    train_flt = DeviceFilter(train_set, dev)
+    val_flt, test_flt = DeviceFilter(val_set, dev), DeviceFilter(test_set, dev)
+    prev_val_mrr = evaluate(model, val_set, tc.eval_batch_size, val_flt)[0]["mrr"]
+    state = None
+    for epoch in range(start_epoch, tc.num_epoches + start_epoch):
+        regularization_coeff = regulizer.step()
+        with timer:
+            train_loss, train_norm = train_one_epoch(model, optimizer, train_flt, tc.train_batch_size, tc.label_smoothig,
+                                                     regularization_coeff=regularization_coeff,
+                                                     max_batches=max_batches_per_epoch)
+        epoch_time = timer.time
+        val_metrics, val_loss = evaluate(model, val_set, tc.eval_batch_size, val_flt)
+        with timer:
+            test_metrics, test_loss = evaluate(model, test_set, tc.eval_batch_size, test_flt)
+        eval_time = timer.time
+        metrics.update(val_metrics, "val")
+        metrics.update(test_metrics, "test")
+        losses.update(train_loss, train_norm, val_loss, test_loss)
+        state = StateDict(model.state_dict(), losses, metrics, epoch, None,
+                          scheduler.state_dict() if scheduler is not None else None)
+        state.save(tc.checkpoint_path, "snapshot", add_epoch=False)
+        if val_metrics["mrr"] - prev_val_mrr > 5e-4:
+            prev_val_mrr = val_metrics["mrr"]
+            state.save(tc.checkpoint_path, f"rk_{model.rank[1]}")
+        lr = optimizer.param_groups[0]["lr"]
+        if scheduler is not None:
+            scheduler.step()
+        record = {"epoch": epoch, "train_loss": train_loss, "val_loss": val_loss, "test_loss": test_loss,
+                  "grad_norm": train_norm, "lr": lr, "reg_coeff": regularization_coeff, "epoch_time": epoch_time,
+                  "eval_time": eval_time}
+        for split, m in (("val", val_metrics), ("test", test_metrics)):
+            for k, v in m.items():
+                record[f"{split}_{k}"] = v
+        if wandb_run is not None:
+            wandb_run.log(record)
+        if log is not None:
+            log(record)
+    return state

@@ -10,8 +10,8 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from ..ops import score_1vN
-from ._tables import TablesCacheMixin
+from ...ops import score_1vN
+from .._tables import TablesCacheMixin
 
 
 class R_TuckER(TablesCacheMixin, nn.Module):

@@ -1,0 +1,159 @@
+"""Riemannian optimizers on the Tucker manifolds: gradient descent, SGD with momentum, Adam.
+
+Our own implementation of what ``src/model/asymmetric/optim.py`` and ``src/model/symmetric/optim.py``
+do through ``tucker_riemopt`` (absent offline; ``riemannian.py`` supplies the geometry), with the same
+class names, constructor arguments, ``fit(loss_fn, x_k, normalize_grad) -> grad norm`` / ``step()``
+protocol, ``.loss`` / ``.direction`` attributes and ``param_groups[0]["lr"]`` handling
+(``train.py:82-85``, ``:213-215`` attaches a torch LR scheduler to them).  One implementation serves both
+manifolds; the per-model modules (``model/asymmetric/optim.py``, ``model/symmetric/optim.py``) bind the
+parameter order of ``train.py:22-24``:  asymmetric ``[core, S, R, O]``, symmetric ``[core, E, R]``.
+
+Defects of the reference not reproduced: the asymmetric ``RGD.step`` unpacks 3
+of 4 parameters and uses shared-factor attributes (A2); ``RiemannianAdam`` is imported by ``train.py``
+but defined nowhere (A1) -- here it is the algorithm of the symmetric module's ``SFTuckerAdam`` for
+either manifold; ``SFTuckerAdam`` hard-codes ``device="cuda"`` (A5) -- the second moment lives on the
+parameters' device.
+"""
+from __future__ import annotations
+
+from typing import Callable, Union
+
+import torch
+from torch.optim import Optimizer
+
+from .riemannian import SFTuckerRiemannian, TuckerRiemannian
+from .tucker import SFTucker, Tucker
+
+
+def _bump(p: torch.Tensor) -> None:
+    """Make a write through ``.data`` visible to autograd's version counter (the relation-table cache of
+    the model closures keys on it)."""
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is not None:
+        inc(p)
+
+
+class _ManifoldOptimizer(Optimizer):
+    """Shared machinery.  ``symmetric`` selects the manifold and the parameter order."""
+
+    symmetric = False
+
+    def __init__(self, params, rank, max_lr, **extra):
+        self.rank = tuple(rank)
+        self.max_lr = max_lr
+        self.lr = max_lr
+        defaults = dict(rank=self.rank, max_lr=self.max_lr, lr=self.lr, **extra)
+        super().__init__(params, defaults)
+        self.direction = None
+        self.loss = None
+
+    @property
+    def geometry(self):
+        return SFTuckerRiemannian if self.symmetric else TuckerRiemannian
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _normalised(self, rgrad, rgrad_norm, normalize_grad):
+        normalize_grad = rgrad_norm if not normalize_grad else normalize_grad
+        # a vanishing gradient (e.g. exactly at an optimum) must not produce NaNs
+        return (normalize_grad / torch.clamp(rgrad_norm, min=torch.finfo(rgrad_norm.dtype).tiny)) * rgrad
+
+    @torch.no_grad()
+    def _retract_and_write(self):
+        lr = self.param_groups[0]["lr"]
+        x_k = self.direction.point
+        moved = (-lr) * self.direction + self.geometry.TangentVector(x_k)
+        x_new = moved.construct().round(self.rank)
+        params = self.param_groups[0]["params"]
+        if self.symmetric:
+            W, E, R = params
+            targets = ((W, x_new.core), (R, x_new.regular_factors[0]), (E, x_new.shared_factor))
+        else:
+            W, S, R, O = params
+            targets = ((W, x_new.core), (R, x_new.factors[0]), (S, x_new.factors[1]), (O, x_new.factors[2]))
+        for p, new in targets:
+            p.data.copy_(new)
+            _bump(p)
+        return x_new
+
+
+class RGD(_ManifoldOptimizer):
+    """Riemannian gradient descent (``asymmetric/optim.py:10-57``, ``symmetric/optim.py:11-59``)."""
+
+    def fit(self, loss_fn: Callable[[Union[Tucker, SFTucker]], torch.Tensor], x_k,
+            normalize_grad: Union[float, bool] = 1.):
+        """Riemannian gradient of ``loss_fn`` at ``x_k``; returns its Frobenius norm.  ``normalize_grad``:
+        ``False`` keeps the gradient's length, a float rescales it to that length."""
+        rgrad, self.loss = self.geometry.grad(loss_fn, x_k)
+        rgrad_norm = rgrad.norm().detach()
+        self.direction = self._normalised(rgrad, rgrad_norm, normalize_grad)
+        return rgrad_norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._retract_and_write()
+
+
+class RSGDwithMomentum(_ManifoldOptimizer):
+    """Riemannian SGD with momentum: the previous direction (kept as an explicit rank-2r tensor) is
+    transported to the new point by projection (``asymmetric/optim.py:60-114``, ``symmetric/optim.py:62-107``)."""
+
+    def __init__(self, params, rank, max_lr, momentum_beta=0.9):
+        super().__init__(params, rank, max_lr, momentum_beta=momentum_beta)
+        self.momentum_beta = momentum_beta
+        self.momentum = None
+
+    def fit(self, loss_fn, x_k, normalize_grad: Union[float, bool] = 1.):
+        geo = self.geometry
+        if self.direction is not None:
+            self.momentum = geo.project(x_k, self.direction)
+        else:
+            self.momentum = geo.TangentVector(x_k, torch.zeros_like(x_k.core))
+        rgrad, self.loss = geo.grad(loss_fn, x_k)
+        rgrad_norm = rgrad.norm().detach()
+        self.direction = self._normalised(rgrad, rgrad_norm, normalize_grad) + self.momentum_beta * self.momentum
+        return rgrad_norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._retract_and_write()
+        self.direction = self.direction.construct()        # explicit tensor: projected at the next point
+
+
+class RiemannianAdam(_ManifoldOptimizer):
+    """Adam with a scalar second moment (the squared gradient norm), first moment transported by projection:
+    the algorithm of ``SFTuckerAdam`` (``symmetric/optim.py:110-167``) on either manifold."""
+
+    def __init__(self, params, rank, max_lr, betas=(0.9, 0.999), eps=1e-8, step_velocity=1):
+        super().__init__(params, rank, max_lr, betas=betas, eps=eps, step_velocity=step_velocity)
+        self.betas = betas
+        self.eps = eps
+        self.step_velocity = step_velocity
+        self.momentum = None
+        self.second_momentum = None
+        self.step_t = 1
+
+    def fit(self, loss_fn, x_k, normalize_grad: Union[float, bool] = 1.):
+        geo = self.geometry
+        rgrad, self.loss = geo.grad(loss_fn, x_k)
+        rgrad_norm = rgrad.norm().detach()
+        b1, b2 = self.betas
+        if self.momentum is not None:
+            self.momentum = geo.project(x_k, self.momentum.construct())
+            self.momentum = b1 * self.momentum + (1 - b1) * rgrad
+        else:
+            self.momentum = (1 - b1) * rgrad
+        if self.second_momentum is None:
+            self.second_momentum = torch.zeros((), device=rgrad_norm.device, dtype=rgrad_norm.dtype)
+        self.second_momentum = b2 * self.second_momentum + (1 - b2) * rgrad_norm ** 2
+        t = self.step_t // self.step_velocity + 1
+        second_corrected = self.second_momentum / (1 - b2 ** t)
+        ratio = (1 - b1 ** t) * torch.sqrt(second_corrected) + self.eps
+        self.direction = (1 / ratio) * self.momentum
+        return rgrad_norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        x_new = self._retract_and_write()
+        # the first moment is a tangent vector at the OLD point: keep it attached there; fit() re-projects
+        del x_new
+        self.step_t += 1

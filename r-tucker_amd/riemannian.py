@@ -1,0 +1,233 @@
+"""Riemannian geometry of the fixed-multilinear-rank Tucker manifolds -- the subset of
+``tucker_riemopt.TuckerRiemannian`` / ``SFTuckerRiemannian`` that the reference's optimizers call
+(``src/model/asymmetric/optim.py:32,52,86-89,107-108``; ``src/model/symmetric/optim.py:34,54,80-83,101-103,
+133-136,160-161``).  ``tucker_riemopt`` 1.0.1 is not vendored and not installable offline, and the
+reference holds no tests for it, so this is our own implementation of the standard geometry
+(Koch-Lubich; Kressner-Steinlechner-Vandereycken), named after the calls the reference makes:
+**parity with the package is unpinned**; correctness is established by identities
+(``tests/test_riemannian.py``): ``construct(TangentVector(x)) == x``, ``project`` idempotent and
+orthogonal, ``grad`` equal to the projection of the Euclidean gradient, gauge conditions, first-order
+retraction.
+
+A point ``x`` is a ``Tucker`` (``SFTucker``) with orthonormal factor columns.  A tangent vector is
+
+    xi = dG x_i U_i  +  sum_i  G x_i dU_i x_{j != i} U_j ,      U_i^T dU_i = 0        (gauge)
+
+(for the shared-factor manifold the shared modes carry ONE ``dE``).  ``construct()`` writes ``xi`` as an
+explicit Tucker tensor of rank 2r: factors ``[U_i, dU_i]``, core a 2a x 2b x 2c block tensor with ``dG`` in
+block (0,0,0) and ``G`` in the three blocks with a single 1.  ``grad`` differentiates
+``loss_fn(construct(dG, dU))`` at ``(dG, dU) = (G, 0)`` -- which is why the scoring closure is evaluated
+at DOUBLED rank during training -- and maps the partial derivatives to the tangent
+space: ``dU_i <- (I - U_i U_i^T) (d/d dU_i) (G_(i) G_(i)^T)^-1``.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from .tucker import SFTucker, Tucker, _mode_dot, _unfold
+
+
+def _core_gram(core: torch.Tensor, mode: int) -> torch.Tensor:
+    u = _unfold(core, mode)
+    return u @ u.transpose(0, 1)
+
+
+def _solve_right(mat: torch.Tensor, gram: torch.Tensor) -> torch.Tensor:
+    """mat @ gram^-1 for a symmetric positive (semi)definite ``gram`` (least-squares pseudo-inverse when
+    the core unfolding is rank-deficient, e.g. a zero core at initialisation)."""
+    try:
+        return torch.linalg.solve(gram, mat.transpose(0, 1)).transpose(0, 1)
+    except RuntimeError:      # singular
+        return mat @ torch.linalg.pinv(gram)
+
+
+def _project_out(U: torch.Tensor, M: torch.Tensor) -> torch.Tensor:
+    """(I - U U^T) M"""
+    return M - U @ (U.transpose(0, 1) @ M)
+
+
+def _block_core(dG: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
+    """The 2a x 2b x 2c core of ``construct``: dG at (0,0,0); G at (1,0,0), (0,1,0), (0,0,1)."""
+    a, b, c = G.shape
+    z_a = G.new_zeros((a, b, c))
+    top = torch.cat([torch.cat([dG, G], dim=2), torch.cat([G, z_a], dim=2)], dim=1)            # (a, 2b, 2c)
+    bot = torch.cat([torch.cat([G, z_a], dim=2), torch.cat([z_a, z_a], dim=2)], dim=1)
+    return torch.cat([top, bot], dim=0)
+
+
+# ======================================================================================================
+# Tucker (asymmetric model: three distinct factors)
+# ======================================================================================================
+class TuckerTangentVector:
+    def __init__(self, point: Tucker, delta_core: Optional[torch.Tensor] = None,
+                 delta_factors: Optional[Sequence[torch.Tensor]] = None):
+        self.point = point
+        self.delta_core = point.core if delta_core is None else delta_core
+        self.delta_factors: List[torch.Tensor] = ([torch.zeros_like(f) for f in point.factors]
+                                                  if delta_factors is None else list(delta_factors))
+
+    def __rmul__(self, a):
+        return TuckerTangentVector(self.point, a * self.delta_core, [a * d for d in self.delta_factors])
+
+    def __neg__(self):
+        return (-1.0) * self
+
+    def __add__(self, other: "TuckerTangentVector"):
+        return TuckerTangentVector(self.point, self.delta_core + other.delta_core,
+                                   [p + q for p, q in zip(self.delta_factors, other.delta_factors)])
+
+    def norm(self) -> torch.Tensor:
+        G = self.point.core
+        s = (self.delta_core * self.delta_core).sum()
+        for i, d in enumerate(self.delta_factors):
+            s = s + ((d.transpose(0, 1) @ d) * _core_gram(G, i)).sum()
+        return torch.sqrt(torch.clamp(s, min=0.0))
+
+    def construct(self) -> Tucker:
+        x = self.point
+        return Tucker(_block_core(self.delta_core, x.core),
+                      [torch.cat([u, d], dim=1) for u, d in zip(x.factors, self.delta_factors)])
+
+
+class TuckerRiemannian:
+    TangentVector = TuckerTangentVector
+
+    @staticmethod
+    def grad(loss_fn: Callable[[Tucker], torch.Tensor], x: Tucker, retain_graph: bool = False):
+        """Riemannian gradient of ``loss_fn`` at ``x`` -> ``(TangentVector, loss value)``."""
+        G = x.core.detach()
+        Us = [u.detach() for u in x.factors]
+        dG = G.clone().requires_grad_(True)
+        dUs = [torch.zeros_like(u).requires_grad_(True) for u in Us]
+        with torch.enable_grad():
+            T = Tucker(_block_core(dG, G), [torch.cat([u, d], dim=1) for u, d in zip(Us, dUs)])
+            loss = loss_fn(T)
+            grads = torch.autograd.grad(loss, [dG] + dUs, retain_graph=retain_graph)
+        g_core, g_fac = grads[0], grads[1:]
+        deltas = [_solve_right(_project_out(u, g), _core_gram(G, i)) for i, (u, g) in enumerate(zip(Us, g_fac))]
+        return TuckerTangentVector(Tucker(G, Us), g_core, deltas), loss.detach()
+
+    @staticmethod
+    def project(x: Tucker, Z: Tucker) -> TuckerTangentVector:
+        """Orthogonal projection of an explicit Tucker tensor ``Z`` onto the tangent space at ``x``."""
+        G = x.core
+        Us = x.factors
+        Ms = [u.transpose(0, 1) @ v for u, v in zip(Us, Z.factors)]          # r_i x k_i
+        dG = Z.core
+        for i, m in enumerate(Ms):
+            dG = _mode_dot(dG, m, i)
+        deltas = []
+        for i, (u, v) in enumerate(zip(Us, Z.factors)):
+            t = Z.core
+            for j, m in enumerate(Ms):
+                if j != i:
+                    t = _mode_dot(t, m, j)
+            w = v @ (_unfold(t, i) @ _unfold(G, i).transpose(0, 1))           # n_i x r_i
+            deltas.append(_solve_right(_project_out(u, w), _core_gram(G, i)))
+        return TuckerTangentVector(x, dG, deltas)
+
+
+# ======================================================================================================
+# SFTucker (symmetric model: modes 1 and 2 share the entity factor)
+# ======================================================================================================
+class SFTuckerTangentVector:
+    def __init__(self, point: SFTucker, delta_core: Optional[torch.Tensor] = None,
+                 delta_regular_factors: Optional[Sequence[torch.Tensor]] = None,
+                 delta_shared_factor: Optional[torch.Tensor] = None):
+        self.point = point
+        self.delta_core = point.core if delta_core is None else delta_core
+        self.delta_regular_factors: List[torch.Tensor] = (
+            [torch.zeros_like(f) for f in point.regular_factors] if delta_regular_factors is None
+            else list(delta_regular_factors))
+        self.delta_shared_factor = (torch.zeros_like(point.shared_factor) if delta_shared_factor is None
+                                    else delta_shared_factor)
+
+    def __rmul__(self, a):
+        return SFTuckerTangentVector(self.point, a * self.delta_core, [a * d for d in self.delta_regular_factors],
+                                     a * self.delta_shared_factor)
+
+    def __neg__(self):
+        return (-1.0) * self
+
+    def __add__(self, other: "SFTuckerTangentVector"):
+        return SFTuckerTangentVector(self.point, self.delta_core + other.delta_core,
+                                     [p + q for p, q in zip(self.delta_regular_factors, other.delta_regular_factors)],
+                                     self.delta_shared_factor + other.delta_shared_factor)
+
+    def _shared_gram(self) -> torch.Tensor:
+        x = self.point
+        nreg = len(x.regular_factors)
+        return sum(_core_gram(x.core, m) for m in range(nreg, nreg + x.num_shared_factors))
+
+    def norm(self) -> torch.Tensor:
+        G = self.point.core
+        s = (self.delta_core * self.delta_core).sum()
+        for i, d in enumerate(self.delta_regular_factors):
+            s = s + ((d.transpose(0, 1) @ d) * _core_gram(G, i)).sum()
+        de = self.delta_shared_factor
+        s = s + ((de.transpose(0, 1) @ de) * self._shared_gram()).sum()
+        return torch.sqrt(torch.clamp(s, min=0.0))
+
+    def construct(self) -> SFTucker:
+        x = self.point
+        assert len(x.regular_factors) == 1 and x.num_shared_factors == 2, "R-TuckER's symmetric model: (R, E, E)"
+        return SFTucker(_block_core(self.delta_core, x.core),
+                        [torch.cat([u, d], dim=1) for u, d in zip(x.regular_factors, self.delta_regular_factors)],
+                        x.num_shared_factors, torch.cat([x.shared_factor, self.delta_shared_factor], dim=1))
+
+
+class SFTuckerRiemannian:
+    TangentVector = SFTuckerTangentVector
+
+    @staticmethod
+    def _shared_gram(G: torch.Tensor, nreg: int, ns: int) -> torch.Tensor:
+        return sum(_core_gram(G, m) for m in range(nreg, nreg + ns))
+
+    @staticmethod
+    def grad(loss_fn: Callable[[SFTucker], torch.Tensor], x: SFTucker, retain_graph: bool = False):
+        G = x.core.detach()
+        Rs = [u.detach() for u in x.regular_factors]
+        E = x.shared_factor.detach()
+        nreg, ns = len(Rs), x.num_shared_factors
+        dG = G.clone().requires_grad_(True)
+        dRs = [torch.zeros_like(u).requires_grad_(True) for u in Rs]
+        dE = torch.zeros_like(E).requires_grad_(True)
+        with torch.enable_grad():
+            T = SFTucker(_block_core(dG, G), [torch.cat([u, d], dim=1) for u, d in zip(Rs, dRs)], ns,
+                         torch.cat([E, dE], dim=1))
+            loss = loss_fn(T)
+            grads = torch.autograd.grad(loss, [dG] + dRs + [dE], retain_graph=retain_graph)
+        g_core, g_reg, g_e = grads[0], grads[1:1 + nreg], grads[-1]
+        d_reg = [_solve_right(_project_out(u, g), _core_gram(G, i)) for i, (u, g) in enumerate(zip(Rs, g_reg))]
+        d_e = _solve_right(_project_out(E, g_e), SFTuckerRiemannian._shared_gram(G, nreg, ns))
+        return SFTuckerTangentVector(SFTucker(G, Rs, ns, E), g_core, d_reg, d_e), loss.detach()
+
+    @staticmethod
+    def project(x: SFTucker, Z: SFTucker) -> SFTuckerTangentVector:
+        G = x.core
+        nreg, ns = len(x.regular_factors), x.num_shared_factors
+        xf, zf = x.factors, Z.factors                        # per-mode lists (shared factor repeated)
+        Ms = [u.transpose(0, 1) @ v for u, v in zip(xf, zf)]
+        dG = Z.core
+        for i, m in enumerate(Ms):
+            dG = _mode_dot(dG, m, i)
+
+        def mode_term(i):
+            t = Z.core
+            for j, m in enumerate(Ms):
+                if j != i:
+                    t = _mode_dot(t, m, j)
+            return zf[i] @ (_unfold(t, i) @ _unfold(G, i).transpose(0, 1))
+
+        d_reg = [_solve_right(_project_out(xf[i], mode_term(i)), _core_gram(G, i)) for i in range(nreg)]
+        w = sum(mode_term(m) for m in range(nreg, nreg + ns))
+        d_e = _solve_right(_project_out(x.shared_factor, w), SFTuckerRiemannian._shared_gram(G, nreg, ns))
+        return SFTuckerTangentVector(x, dG, d_reg, d_e)
+
+
+def set_backend(name: str = "pytorch") -> None:
+    """``tucker_riemopt.set_backend`` (train.py:10,197): torch is the only backend here."""
+    if name not in ("pytorch", "torch"):
+        raise ValueError(f"r_tucker_amd runs on torch only, got backend {name!r}")

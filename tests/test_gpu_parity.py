@@ -242,11 +242,15 @@ def test_empty_batch_and_errors(rt):
     # CPU tensors: no silent fallback
     with pytest.raises(RuntimeError):
         rt.score_1vN(*[torch.from_numpy(x) for x in (core, R, S, O)], torch.tensor([0]), torch.tensor([0]))
-    # out-of-range ids never fault; the error word reports them
+    # out-of-range ids never fault; they raise IndexError like the reference (default "strict" policy) --
+    # or, deferred, at the caller's own synchronisation point
     rt.check_device_errors()
-    rt.score_1vN(*d, torch.tensor([0, 50]).cuda(), torch.tensor([0, 1]).cuda())
     with pytest.raises(IndexError):
-        rt.check_device_errors()
+        rt.score_1vN(*d, torch.tensor([0, 50]).cuda(), torch.tensor([0, 1]).cuda())
+    with rt.index_check("deferred"):
+        rt.score_1vN(*d, torch.tensor([0, 50]).cuda(), torch.tensor([0, 1]).cuda())
+        with pytest.raises(IndexError):
+            rt.check_device_errors()
     rt.score_1vN(*d, torch.tensor([0, 49]).cuda(), torch.tensor([0, 1]).cuda())
     rt.check_device_errors()
 
