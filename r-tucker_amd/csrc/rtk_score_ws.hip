@@ -1,4 +1,6 @@
 // Launcher of the wave-specialised persistent split-fp16 score kernel (rtk_score_ws_kernel.h).
+#include <stdlib.h>
+
 #include "rtk_score_ws_kernel.h"
 
 namespace {
@@ -13,7 +15,9 @@ bool launch_v(const unsigned char *qp, int B, const float *O, int N, int c, floa
     // one resident workgroup per CU; the kernel cuts the (entity tile x query tile) space evenly
     const int64_t units = rtk_cdiv(N, 128) * rtk_cdiv(B, 32);
     const unsigned grid = (unsigned)(units < 256 ? units : 256);
-    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<KS, SG, OV>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld);
+    static const int xcd_remap = getenv("RTK_WS_NOXCD") ? 0 : 1;   // A/B: XCD-aware schedule of the remainder tiles
+    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<KS, SG, OV>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld,
+                       xcd_remap);
     return true;
 }
 

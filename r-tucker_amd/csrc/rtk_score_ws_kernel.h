@@ -59,8 +59,13 @@ struct Sched {
     int ta, ta_end;            // whole tiles [ta, ta_end)
     int rem_tile0;             // first remainder tile
     int lin, lin_end;          // remainder units, linearised (tile - rem_tile0) * n_mt + query tile
-    __device__ __forceinline__ void init(int B_, int N_, int c_, int w, int W) {
+    __device__ __forceinline__ void init(int B_, int N_, int c_, int w, int W, bool xcd_remap) {
         B = B_; N = N_; c = c_;
+        // Workgroups are dealt round-robin to the 8 XCDs (w % 8 says which share one).  The remainder
+        // tiles are each swept by several NEIGHBOURING schedule slots: make neighbours share an XCD, so the
+        // tile is fetched from HBM once and served to the others by that XCD's L2 (speed only: any
+        // placement gives the same scores).
+        if (xcd_remap && (W & 7) == 0) w = (w & 7) * (W >> 3) + (w >> 3);
         n_mt = (B + 31) / 32;
         const int T = (N + 127) / 128;
         const int base = T / W;
@@ -365,13 +370,13 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
 template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0>
 __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
-    float *__restrict__ out, int64_t ld_out) {
+    float *__restrict__ out, int64_t ld_out, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *const stg = lds;
     unsigned char *const oreg = lds + 2 * tile_bytes<KS>();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     Sched sc;
-    sc.init(B, N, c, blockIdx.x, gridDim.x);
+    sc.init(B, N, c, blockIdx.x, gridDim.x, xcd_remap != 0);
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
     if (__builtin_amdgcn_readfirstlane(wave) < 4) m_role<KS, STAMP, XP, O_VEC, SIGMOID>(sc, q_packed, stg, oreg, lane, wave & 3, t & 255);
     else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, wave & 3, t & 255);

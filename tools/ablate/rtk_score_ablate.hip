@@ -1,6 +1,7 @@
 // Ablation build of the split-fp16 score kernel (NOT part of librtucker_hip.so): the same
 // kernel source instantiated with compile-time ablation masks, to see where the time goes.
 // Build: tools/ablate/build.sh -> tools/ablate/librtk_ablate.so
+#include <stdlib.h>
 #include "rtk_score_split_kernel.h"
 #include "rtk_score_ws_kernel.h"
 
@@ -41,7 +42,7 @@ static int ws_go(const void *qp, int64_t B, int c, const float *O, int64_t N, fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<13, 2, true, true, XP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((rtk_ws::score_ws_kernel<13, 2, true, true, XP>), dim3(grid), dim3(512), smem, (hipStream_t)stream,
-                       (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld);
+                       (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld, getenv("RTK_WS_NOXCD") ? 0 : 1);
     return (int)hipGetLastError();
 }
 extern "C" int rtk_ablate_ws(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld,

@@ -54,6 +54,8 @@ def main(argv=None):
     parser.add_argument("--max-batches", type=int, default=None, help="cap the batches per epoch (smoke runs)")
     parser.add_argument("--rank", type=int, nargs=3, default=None, help="override model_cfg.manifold_rank")
     parser.add_argument("--checkpoint-path", default=None, help="override train_cfg.checkpoint_path")
+    parser.add_argument("--set", dest="overrides", action="append", default=[], metavar="SECTION.FIELD=VALUE",
+                        help="override a configuration field, e.g. --set train_cfg.learning_rate=50 (repeatable)")
     args = parser.parse_args(argv)
     if args.mode not in ("symmetric", "asymmetric"):
         raise SystemExit("--mode must be symmetric or asymmetric")
@@ -76,6 +78,12 @@ def main(argv=None):
         cfg.train_cfg.num_epoches = args.epochs
     if args.rank is not None:
         cfg.model_cfg.manifold_rank = tuple(args.rank)
+    for item in args.overrides:
+        key, _, raw = item.partition("=")
+        section, _, name = key.partition(".")
+        target = getattr(cfg, section)
+        old = getattr(target, name)
+        setattr(target, name, type(old)(raw) if not isinstance(old, (tuple, bool)) else json.loads(raw))
     tc = cfg.train_cfg
     if args.checkpoint_path is not None:
         tc.checkpoint_path = args.checkpoint_path
