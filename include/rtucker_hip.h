@@ -53,6 +53,22 @@ typedef enum rtk_dtype {
 #define RTK_SCORE_SIGMOID 1u      /* apply sigmoid (R_TuckER.py:48); else raw logits  */
 #define RTK_SCORE_EXACT_F32 2u    /* fp32 operands: force the exact-fp32 MFMA kernel   */
                                   /* instead of the split-fp16 (hi/lo) MFMA kernel     */
+/*
+ * Precision of the default fp32 score kernel (rtk_score_packed_f32, "split-fp16"): every operand row
+ * (a query vector v_d, an entity row O[j]) is scaled by a power of two so that its LARGEST element
+ * lands in [2^14, 2^15) and each element is split x = hi + lo into two fp16 values (~22 significand
+ * bits relative to the ROW MAXIMUM); v.o ~= vh.oh + vh.ol + vl.oh, accumulated in fp32 (the vl.ol
+ * term, 2^-22 relative, is dropped).  The guarantee is therefore NORMWISE PER ROW, not element-wise:
+ *     |dz[d,j]|  <~  2^-21 * K * max|v_d| * max|O_j|
+ * -- elements much smaller than their row's maximum lose RELATIVE precision: an element keeps all ~22
+ * bits down to 2^-17 of the row maximum, then one bit less per factor of two (fp16 subnormals) to 11
+ * bits at 2^-28, and is dropped entirely below 2^-39 of the row maximum -- which
+ * does not matter for a dot product dominated by the large elements but is not what an exact fp32
+ * product gives for rows of extreme dynamic range.  Measured: the same error against float64 as the
+ * reference's CPU sgemm at rank (10,200,200) (3-5e-6 relative; tests/test_gpu_parity.py,
+ * test_wide_dynamic_range_rows).  RTK_SCORE_EXACT_F32 selects v_mfma_f32_32x32x2_f32 (bitwise an
+ * fmaf chain) at 1/5 of the throughput when element-wise fp32 behaviour is required.
+ */
 #define RTK_SCORE_SIGMOID_FAST 4u /* with RTK_SCORE_SIGMOID: 1 / (1 + 2^(-z log2 e)) on  */
                                   /* v_exp_f32 + v_rcp_f32 (1 ulp each) instead of expf */
                                   /* + IEEE divide                                      */
@@ -291,6 +307,8 @@ int rtk_filtered_rank_partial_f32(const float *P, int64_t batch, int64_t n_local
  *   rtk_bce_grad_f32  in place  P[d,j] <- (P[d,j] - y[d,j]) * grad_loss[0] * scale : with
  *                     scale = 1 / (batch * n_ent) this is d loss / d logits (P = sigmoid(logits)),
  *                     the left operand of the dO / dv GEMMs.  grad_loss is a DEVICE scalar.
+ *                     Entries whose fp32 score is saturated (exactly 1.0f or 0.0f) become 0, as in the
+ *                     reference's autograd (BCELoss backward x logistic backward = (p - y) * [p(1-p) / max(p(1-p), 1e-12)]).
  */
 int rtk_bce_rows_f32(const float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
                      const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,

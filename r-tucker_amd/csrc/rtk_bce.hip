@@ -6,6 +6,10 @@
 //   rtk_bce_rows_f32 : per-row sum of BCE terms           (forward:  loss = sum / (B * N))
 //   rtk_bce_grad_f32 : P <- (P - y) * g * scale, in place (backward: d loss / d logits, because
 //                      d BCE / d z = p - y for p = sigmoid(z)), ready for the dO / dv GEMMs.
+//                      Where the fp32 score is SATURATED (p == 1.0f for z >~ 16.64, p == 0.0f) the result is 0:
+//                      that is what the reference's autograd returns there (BCELoss' backward divides
+//                      by max(p (1 - p), 1e-12) and the logistic's backward multiplies by p (1 - p) = 0),
+//                      and a trained model does saturate.
 // Both are one pass over the B x N scores plus a pass over the few positives.
 // The CSR must hold every object of a pair ONCE (evaluation.DeviceFilter de-duplicates).
 #include "rtk_common.h"
@@ -56,7 +60,30 @@ __global__ __launch_bounds__(256) void bce_rows_kernel(const float *__restrict__
     if (t == 0) rows[d] = -(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
-// P <- (P - t0) * g * scale for every element (grid-stride over rows x column chunks)
+// Pass 1, the positives (their target is t0 + dt): p <- p - dt unless p is saturated (p == 1.0f stays 1.0f and
+// is then zeroed by pass 2 like a saturated negative; an unsaturated positive lands in (-dt, 1 - dt), never
+// on 1.0f).  One workgroup per row.
+__global__ __launch_bounds__(64) void bce_grad_pos_kernel(float *__restrict__ P, int N, int64_t ld, float dt,
+                                                          const int64_t *__restrict__ pair_slot,
+                                                          const int64_t *__restrict__ pair_ptr,
+                                                          const int64_t *__restrict__ pair_obj) {
+    const int d = blockIdx.x;
+    float *row = P + (int64_t)d * ld;
+    const int64_t sl = pair_slot[d];
+    for (int64_t i = pair_ptr[sl] + threadIdx.x; i < pair_ptr[sl + 1]; i += 64) {
+        const int64_t j = pair_obj[i];
+        if (j >= 0 && j < N) {
+            const float p = row[j];
+            if (p != 1.0f && p != 0.0f) row[j] = p - dt;
+        }
+    }
+}
+
+// Pass 2, every element: x <- (x - t0) * g * scale, or 0 where the score was saturated (x == 1.0f / 0.0f)
+// (grid-stride over rows x column chunks)
+__device__ __forceinline__ float bce_grad_one(float x, float t0, float s) {
+    return (x == 1.0f || x == 0.0f) ? 0.0f : (x - t0) * s;
+}
 template <bool VEC>
 __global__ __launch_bounds__(256) void bce_grad_all_kernel(float *__restrict__ P, int B, int N, int64_t ld, float t0,
                                                            const float *__restrict__ g, float scale) {
@@ -68,28 +95,12 @@ __global__ __launch_bounds__(256) void bce_grad_all_kernel(float *__restrict__ P
         for (int q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
             f32x4 x = reinterpret_cast<f32x4 *>(row)[q];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = (x[e] - t0) * s;
+            for (int e = 0; e < 4; ++e) x[e] = bce_grad_one(x[e], t0, s);
             reinterpret_cast<f32x4 *>(row)[q] = x;
         }
-        for (int j = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) row[j] = (row[j] - t0) * s;
+        for (int j = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) row[j] = bce_grad_one(row[j], t0, s);
     } else {
-        for (int j = blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) row[j] = (row[j] - t0) * s;
-    }
-}
-
-// the positives: their target was t0 + dt
-__global__ __launch_bounds__(64) void bce_grad_pos_kernel(float *__restrict__ P, int N, int64_t ld, float dt,
-                                                          const float *__restrict__ g, float scale,
-                                                          const int64_t *__restrict__ pair_slot,
-                                                          const int64_t *__restrict__ pair_ptr,
-                                                          const int64_t *__restrict__ pair_obj) {
-    const int d = blockIdx.x;
-    const float s = g[0] * scale * dt;
-    float *row = P + (int64_t)d * ld;
-    const int64_t sl = pair_slot[d];
-    for (int64_t i = pair_ptr[sl] + threadIdx.x; i < pair_ptr[sl + 1]; i += 64) {
-        const int64_t j = pair_obj[i];
-        if (j >= 0 && j < N) row[j] -= s;
+        for (int j = blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) row[j] = bce_grad_one(row[j], t0, s);
     }
 }
 
@@ -129,9 +140,9 @@ extern "C" int rtk_bce_grad_f32(float *P, int64_t batch, int64_t n_ent, int64_t 
     const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
     const unsigned gx = (unsigned)(rtk_cdiv(n_ent, 1024 * 4) < 1 ? 1 : rtk_cdiv(n_ent, 1024 * 4));
     dim3 grid(gx < 64 ? gx : 64, (unsigned)batch);
+    hipLaunchKernelGGL(bce_grad_pos_kernel, dim3((unsigned)batch), dim3(64), 0, st, P, (int)n_ent, ld, dt, pair_slot, pair_ptr,
+                       pair_obj);
     if (vec) hipLaunchKernelGGL((bce_grad_all_kernel<true>), grid, dim3(256), 0, st, P, (int)batch, (int)n_ent, ld, t0, grad_loss, scale);
     else hipLaunchKernelGGL((bce_grad_all_kernel<false>), grid, dim3(256), 0, st, P, (int)batch, (int)n_ent, ld, t0, grad_loss, scale);
-    hipLaunchKernelGGL(bce_grad_pos_kernel, dim3((unsigned)batch), dim3(64), 0, st, P, (int)n_ent, ld, dt, grad_loss, scale,
-                       pair_slot, pair_ptr, pair_obj);
     return rtk_check_launch("rtk_bce_grad_f32");
 }

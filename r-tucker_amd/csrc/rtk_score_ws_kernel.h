@@ -59,22 +59,23 @@ struct Sched {
     int ta, ta_end;            // whole tiles [ta, ta_end)
     int rem_tile0;             // first remainder tile
     int lin, lin_end;          // remainder units, linearised (tile - rem_tile0) * n_mt + query tile
-    __device__ __forceinline__ void init(int B_, int N_, int c_, int w, int W, bool xcd_remap) {
+    __device__ __forceinline__ void init(int B_, int N_, int c_, int w, int W, int xcd_remap) {
         B = B_; N = N_; c = c_;
         // Workgroups are dealt round-robin to the 8 XCDs (w % 8 says which share one).  The remainder
         // tiles are each swept by several NEIGHBOURING schedule slots: make neighbours share an XCD, so the
         // tile is fetched from HBM once and served to the others by that XCD's L2 (speed only: any
-        // placement gives the same scores).
-        if (xcd_remap && (W & 7) == 0) w = (w & 7) * (W >> 3) + (w >> 3);
+        // placement gives the same scores).  xcd_remap: 0 = off, 1 = both phases, 2 = remainder phase only.
+        const int wx = (xcd_remap && (W & 7) == 0) ? (w & 7) * (W >> 3) + (w >> 3) : w;
+        const int ww = xcd_remap == 1 ? wx : w;
         n_mt = (B + 31) / 32;
         const int T = (N + 127) / 128;
         const int base = T / W;
-        ta = w * base;
+        ta = ww * base;
         ta_end = ta + base;
         rem_tile0 = base * W;
         const int64_t Ur = (int64_t)(T - rem_tile0) * n_mt;
-        lin = (int)(Ur * w / W);
-        lin_end = (int)(Ur * (w + 1) / W);
+        lin = (int)(Ur * wx / W);
+        lin_end = (int)(Ur * (wx + 1) / W);
     }
     __device__ __forceinline__ bool peek(int &tile) const {
         if (ta < ta_end) { tile = ta; return true; }
@@ -256,13 +257,21 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int KS, int SIGMOID, bool STAMP, unsigned XP>
+// HSPLIT: the helper waves split their two jobs -- waves 4,5 stage the query tiles (global -> registers -> LDS),
+// waves 6,7 store the scores (two M waves' exchange slots each).  A wave's vector-memory operations
+// retire IN ORDER (one vmcnt counter): a helper that waits for its staging loads also waits for every
+// score store it issued before them, i.e. for the write acknowledgements of the whole previous tile --
+// under load those take longer than a tile-step, and the barrier passes that wait on to the MFMA waves.
+// A wave that only stores never waits on vmcnt inside the sweep.
+template <int KS, int SIGMOID, bool STAMP, unsigned XP, bool HSPLIT>
 __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict__ q_packed,
                                        const float *__restrict__ O, float *__restrict__ out, int64_t ld_out,
                                        unsigned char *stg, unsigned char *oreg, int lane, int w4, int ht) {
     constexpr int TILE_BYTES = tile_bytes<KS>();
     constexpr int CHUNKS = TILE_BYTES / 16;
-    constexpr int NLD = (CHUNKS + 255) / 256;   // staging 16-B chunks per helper thread
+    constexpr int NST = HSPLIT ? 128 : 256;     // threads that stage
+    constexpr int NLD = (CHUNKS + NST - 1) / NST;   // staging 16-B chunks per staging thread
+    const bool stager = !HSPLIT || w4 < 2, storer = !HSPLIT || w4 >= 2;
     constexpr int NOR = 2 * KS;                 // raw O 16-B pieces per helper thread (32*c/256 <= 2*KS)
     const int r = lane & 31, h = lane >> 5, c = sc.c, N = sc.N, B = sc.B;
     u32x4 oraw[NOR];
@@ -279,19 +288,22 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
         }
     };
     u32x4 sreg[NLD];
+    const int st_t = HSPLIT ? (ht & 127) : ht;
     auto stage_load = [&](int mt) {
+        if (!stager) return;
         const u32x4 *src = reinterpret_cast<const u32x4 *>(q_packed + (int64_t)mt * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int ch = i * 256 + ht;
+            const int ch = i * NST + st_t;
             if (i + 1 < NLD || ch < CHUNKS) sreg[i] = src[ch];
         }
     };
     auto stage_store = [&](int buf) {
+        if (!stager) return;
         u32x4 *dst = reinterpret_cast<u32x4 *>(stg + buf * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int ch = i * 256 + ht;
+            const int ch = i * NST + st_t;
             if (i + 1 < NLD || ch < CHUNKS) dst[ch] = sreg[i];
         }
     };
@@ -320,7 +332,14 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
         if (more) load_oraw(next_tile);              // stays in registers for the whole sweep
         __syncthreads();                             // S2
         if (STAMP && lane == 0 && g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-        const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
+        // columns this wave stores: its own M wave's 32 (all four helpers store), or two M waves' (HSPLIT storers)
+        constexpr int NSL = HSPLIT ? 2 : 1;
+        unsigned voffs[NSL];
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) {
+            const int jq = HSPLIT ? ntile * 128 + ((w4 & 1) * 2 + q) * 32 + r : j;
+            voffs[q] = (jq < N) ? (unsigned)((4 * h * ld_out + jq) * 4) : 0x80000000u;
+        }
         for (int i = 0; i < cnt + 2; ++i) {
             const bool st = STAMP && i == 5 && lane == 0;
             unsigned long long *sp = g_ws_stamps + (blockIdx.x * 8 + 4 + w4) * 8;
@@ -330,29 +349,33 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             // iteration ago -- and its LDS writes come last.
             const bool stage = i + 1 < cnt;
             if (stage) stage_load(mt0 + i + 1);
-            if (i >= 2 && !(XP & 2)) {               // scores of tile i-2: logistic + stores
+            if (i >= 2 && !(XP & 2) && storer) {     // scores of tile i-2: logistic + stores
                 const int mt = mt0 + i - 2;
-                const f32x4 *exr = reinterpret_cast<const f32x4 *>(oreg + (i & 1) * EX_BYTES + w4 * 4096);
                 const int rows = min(32, B - mt * 32);
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     out + (int64_t)mt * 32 * ld_out, 0, (unsigned)(rows * ld_out * 4), 0x00020000);
-                // stage by stage over all 16 values: written element by element the compiler chains
-                // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
-                float zz[16], pp[16];
+#pragma nounroll
+                for (int q = 0; q < NSL; ++q) {
+                    const int mw = HSPLIT ? (w4 & 1) * 2 + q : w4;      // the M wave whose slot this is
+                    const f32x4 *exr = reinterpret_cast<const f32x4 *>(oreg + (i & 1) * EX_BYTES + mw * 4096);
+                    // stage by stage over all 16 values: written element by element the compiler chains
+                    // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
+                    float zz[16], pp[16];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 z = exr[g * 64 + lane];
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 z = exr[g * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q];
-                }
-                // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
+                        for (int e = 0; e < 4; ++e) zz[4 * g + e] = z[e];
+                    }
+                    // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
-                unsigned off = voff;
+                    for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
+                    unsigned off = (HSPLIT && q) ? voffs[NSL - 1] : voffs[0];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
-                    off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                    for (int e = 0; e < 16; ++e) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
+                        off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                    }
                 }
             }
             if (st) sp[1] = __builtin_amdgcn_s_memtime();
@@ -367,7 +390,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
 
 // O_VEC: c % 4 == 0 and O 16-B aligned (compile-time so the scalar fallback's address arithmetic
 // is not hoisted into -- and spilled by -- the vector build)
-template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0>
+template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0, bool HSPLIT = false>
 __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
     float *__restrict__ out, int64_t ld_out, int xcd_remap) {
@@ -376,10 +399,11 @@ __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     unsigned char *const oreg = lds + 2 * tile_bytes<KS>();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     Sched sc;
-    sc.init(B, N, c, blockIdx.x, gridDim.x, xcd_remap != 0);
+    sc.init(B, N, c, blockIdx.x, gridDim.x, xcd_remap);
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
-    if (__builtin_amdgcn_readfirstlane(wave) < 4) m_role<KS, STAMP, XP, O_VEC, SIGMOID>(sc, q_packed, stg, oreg, lane, wave & 3, t & 255);
-    else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, wave & 3, t & 255);
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);     // in an SGPR: role tests are scalar branches
+    if (uwave < 4) m_role<KS, STAMP, XP, O_VEC, SIGMOID>(sc, q_packed, stg, oreg, lane, uwave & 3, t & 255);
+    else h_role<KS, SIGMOID, STAMP, XP, HSPLIT>(sc, q_packed, O, out, ld_out, stg, oreg, lane, uwave & 3, t & 255);
 }
 
 }  // namespace rtk_ws

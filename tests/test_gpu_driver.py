@@ -45,17 +45,44 @@ def test_train_py_short_run(tmp_path, capsys, mode, optim):
     assert os.path.exists(os.path.join(str(tmp_path), f"rk_24_final.pth"))
 
 
-def test_descends_with_a_small_step(tmp_path, capsys):
-    """Without the norm penalty and with a moderate step the BCE part goes down epoch over epoch."""
-    import train
-    state = train.main(["--mode", "asymmetric", "--optim", "rsgd", "--seed", "1", "--data", os.path.join(ROOT, "data", "WN18RR") + "/",
-                        "--config", "wn18rr_readme", "--epochs", "3", "--max-batches", "20", "--rank", "6", "24", "24",
-                        "--checkpoint-path", str(tmp_path), "--set", "train_cfg.learning_rate=300",
-                        "--set", "train_cfg.base_regularization_coeff=1e-30", "--set", "train_cfg.final_regularization_coeff=1e-31",
-                        "--set", "train_cfg.scheduler_step=1.0"])
-    capsys.readouterr()
-    tl = state.losses.train
-    assert tl[0] < 0.6932 and tl[2] < tl[1] < tl[0], tl                  # starts at ln 2 (all scores 0.5) and descends
+@pytest.mark.parametrize("mode", ["asymmetric", "symmetric"])
+def test_riemannian_gradient_through_the_hip_loss_is_a_descent_direction(mode):
+    """loss_fn of train.py:79 built on the HIP loss (CSR targets, doubled-rank construct differentiated by the
+    native backward): a short step along -grad followed by the retraction lowers the loss by about
+    t * |grad|^2, and the retracted point stays on the manifold."""
+    import r_tucker_amd as rt
+    from r_tucker_amd import driver
+    from r_tucker_amd.data import Data, KG_dataset
+    from r_tucker_amd.riemannian import SFTuckerRiemannian, TuckerRiemannian
+    torch.manual_seed(5)
+    data = Data(os.path.join(ROOT, "data", "WN18RR") + "/", reverse=True)
+    train_set = KG_dataset(data, data.train_data, label_smoothing=0.1)
+    flt = rt.DeviceFilter(train_set, "cuda")
+    rank = (6, 24, 24)
+    Model = rt.SymmetricR_TuckER if mode == "symmetric" else rt.AsymmetricR_TuckER
+    model = Model((len(data.entities), len(data.relations)), rank)
+    model.init()
+    with torch.no_grad():
+        model.core.mul_(2000.0)            # logits of order one: the loss surface has curvature to see
+    model.cuda()
+    geo = SFTuckerRiemannian if mode == "symmetric" else TuckerRiemannian
+    ids = torch.arange(1000, 1512, device="cuda")
+    f = flt.features[ids]
+    loss_fn = driver.batch_loss_fn(model, f[:, 0].contiguous(), f[:, 1].contiguous(), flt, ids, 0.1, 1e-9)
+    x = driver.extract_tensor(model)
+    rgrad, loss0 = geo.grad(loss_fn, x)
+    gn = rgrad.norm().item()
+    assert gn > 0 and torch.isfinite(loss0)
+    with torch.no_grad():
+        drops = []
+        for t in (0.02 * x.norm().item() / gn, 0.005 * x.norm().item() / gn):
+            y = (((-t) * rgrad) + geo.TangentVector(rgrad.point)).construct().round(rank)
+            drops.append((loss0 - loss_fn(y)).item() / (t * gn * gn))
+            for w in ([y.shared_factor] + y.regular_factors if mode == "symmetric" else y.factors):
+                w = w.double()
+                assert (w.T @ w - torch.eye(w.shape[1], dtype=torch.float64, device=w.device)).abs().max().item() < 5e-5
+    # first order: (loss(x) - loss(R(x - t g))) / (t |g|^2) -> 1 as t -> 0
+    assert all(0.5 < d < 1.5 for d in drops), drops
 
 
 def test_one_full_epoch_at_the_readme_rank(tmp_path, capsys):

@@ -321,8 +321,16 @@ def test_gemm_splitk_against_float64(rt):
     Bm = rng.standard_normal((K, N)).astype(np.float32)      # B(n, k) = Bm[k, n]: M-major
     dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(Bm).cuda()
     C = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")   # must be overwritten, not accumulated into
+    ws = torch.empty(lib.rtk_gemm_f32_splitk_workspace_bytes(M, N, 9), dtype=torch.uint8, device="cuda")
     rc = lib.rtk_gemm_f32_splitk(dA.data_ptr(), 1, K, dB.data_ptr(), 0, N, C.data_ptr(), N, M, N, K, 9,
-                                 torch.cuda.current_stream().cuda_stream)
+                                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.rtk_last_error_string()
     ref = A.astype(np.float64) @ Bm.astype(np.float64)
     assert np.max(np.abs(C.cpu().numpy() - ref)) < 2e-3
+    # fixed summation order: a second run gives the same bits; a short workspace is refused
+    C2 = torch.empty_like(C)
+    assert lib.rtk_gemm_f32_splitk(dA.data_ptr(), 1, K, dB.data_ptr(), 0, N, C2.data_ptr(), N, M, N, K, 9,
+                                   ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.equal(C, C2)
+    assert lib.rtk_gemm_f32_splitk(dA.data_ptr(), 1, K, dB.data_ptr(), 0, N, C2.data_ptr(), N, M, N, K, 9,
+                                   ws.data_ptr(), 16, torch.cuda.current_stream().cuda_stream) == -2
