@@ -257,21 +257,19 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
-// HSPLIT: the helper waves split their two jobs -- waves 4,5 stage the query tiles (global -> registers -> LDS),
-// waves 6,7 store the scores (two M waves' exchange slots each).  A wave's vector-memory operations
-// retire IN ORDER (one vmcnt counter): a helper that waits for its staging loads also waits for every
-// score store it issued before them, i.e. for the write acknowledgements of the whole previous tile --
-// under load those take longer than a tile-step, and the barrier passes that wait on to the MFMA waves.
-// A wave that only stores never waits on vmcnt inside the sweep.
-template <int KS, int SIGMOID, bool STAMP, unsigned XP, bool HSPLIT>
+// SDEEP: the helpers keep TWO query tiles in flight (tile i+2 is requested while tile i is being multiplied),
+// in two register sets that alternate (the iteration loop is unrolled by two so that each set is a fixed group
+// of registers).  With one tile in flight the L2 round trip of tile i+1 -- queued behind the score stores of
+// the same wave, and a wave's vector-memory operations retire in order -- has to fit into one tile-step.
+// (A/B'd and rejected: splitting the helpers into two staging and two storing waves, so that the storing
+// waves never wait on vmcnt -- 43.3 us against 42.2 us.)
+template <int KS, int SIGMOID, bool STAMP, unsigned XP, bool SDEEP>
 __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict__ q_packed,
                                        const float *__restrict__ O, float *__restrict__ out, int64_t ld_out,
                                        unsigned char *stg, unsigned char *oreg, int lane, int w4, int ht) {
     constexpr int TILE_BYTES = tile_bytes<KS>();
     constexpr int CHUNKS = TILE_BYTES / 16;
-    constexpr int NST = HSPLIT ? 128 : 256;     // threads that stage
-    constexpr int NLD = (CHUNKS + NST - 1) / NST;   // staging 16-B chunks per staging thread
-    const bool stager = !HSPLIT || w4 < 2, storer = !HSPLIT || w4 >= 2;
+    constexpr int NLD = (CHUNKS + 255) / 256;   // staging 16-B chunks per helper thread
     constexpr int NOR = 2 * KS;                 // raw O 16-B pieces per helper thread (32*c/256 <= 2*KS)
     const int r = lane & 31, h = lane >> 5, c = sc.c, N = sc.N, B = sc.B;
     u32x4 oraw[NOR];
@@ -287,23 +285,20 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             oraw[i] = x;
         }
     };
-    u32x4 sreg[NLD];
-    const int st_t = HSPLIT ? (ht & 127) : ht;
-    auto stage_load = [&](int mt) {
-        if (!stager) return;
+    u32x4 sregA[NLD], sregB[SDEEP ? NLD : 1];
+    auto stage_load = [&](u32x4 *sreg, int mt) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(q_packed + (int64_t)mt * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int ch = i * NST + st_t;
+            const int ch = i * 256 + ht;
             if (i + 1 < NLD || ch < CHUNKS) sreg[i] = src[ch];
         }
     };
-    auto stage_store = [&](int buf) {
-        if (!stager) return;
+    auto stage_store = [&](const u32x4 *sreg, int buf) {
         u32x4 *dst = reinterpret_cast<u32x4 *>(stg + buf * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int ch = i * NST + st_t;
+            const int ch = i * 256 + ht;
             if (i + 1 < NLD || ch < CHUNKS) dst[ch] = sreg[i];
         }
     };
@@ -321,68 +316,68 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
         // first query tile of the sweep: requested BEFORE the O tile goes to LDS, so its L2 round trip
         // runs beside that write and the S1 wait instead of after them (it took longer than the M
         // waves' conversion and held S2 back)
-        stage_load(mt0);
+        stage_load(sregA, mt0);
 #pragma unroll
         for (int i = 0; i < NOR; ++i) {
             const int pc = i * 256 + ht;
             if (pc < 32 * c) reinterpret_cast<u32x4 *>(oreg)[pc] = oraw[i];
         }
         __syncthreads();                             // S1
-        stage_store(0);
+        stage_store(sregA, 0);
+        if (SDEEP && cnt > 1) stage_load(sregB, mt0 + 1);   // tile 1 -> set B (odd tiles live in B, even ones in A)
         if (more) load_oraw(next_tile);              // stays in registers for the whole sweep
         __syncthreads();                             // S2
         if (STAMP && lane == 0 && g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-        // columns this wave stores: its own M wave's 32 (all four helpers store), or two M waves' (HSPLIT storers)
-        constexpr int NSL = HSPLIT ? 2 : 1;
-        unsigned voffs[NSL];
-#pragma unroll
-        for (int q = 0; q < NSL; ++q) {
-            const int jq = HSPLIT ? ntile * 128 + ((w4 & 1) * 2 + q) * 32 + r : j;
-            voffs[q] = (jq < N) ? (unsigned)((4 * h * ld_out + jq) * 4) : 0x80000000u;
-        }
-        for (int i = 0; i < cnt + 2; ++i) {
+        const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
+        // one iteration; `lreg`: the register set this iteration loads into, `sreg`: the set it writes to LDS
+        auto iteration = [&](int i, u32x4 *lreg, const u32x4 *sreg) {
             const bool st = STAMP && i == 5 && lane == 0;
             unsigned long long *sp = g_ws_stamps + (blockIdx.x * 8 + 4 + w4) * 8;
             if (st) sp[0] = __builtin_amdgcn_s_memtime();
-            // Query tile i+1: its loads go out first -- in the in-order vmcnt stream they are OLDER than
-            // this iteration's score stores, so the wait at the bottom only covers stores issued a whole
-            // iteration ago -- and its LDS writes come last.
-            const bool stage = i + 1 < cnt;
-            if (stage) stage_load(mt0 + i + 1);
-            if (i >= 2 && !(XP & 2) && storer) {     // scores of tile i-2: logistic + stores
+            // The staging loads go out first -- in the in-order vmcnt stream they are OLDER than this
+            // iteration's score stores, so the wait at the bottom only covers stores issued a whole iteration
+            // ago (SDEEP: two iterations ago) -- and the LDS writes come last.
+            const bool stage = i + 1 < cnt;                       // tile i+1 goes to LDS at the bottom
+            if (SDEEP ? (i + 2 < cnt) : stage) stage_load(lreg, mt0 + i + (SDEEP ? 2 : 1));
+            if (i >= 2 && !(XP & 2)) {               // scores of tile i-2: logistic + stores
                 const int mt = mt0 + i - 2;
+                const f32x4 *exr = reinterpret_cast<const f32x4 *>(oreg + (i & 1) * EX_BYTES + w4 * 4096);
                 const int rows = min(32, B - mt * 32);
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     out + (int64_t)mt * 32 * ld_out, 0, (unsigned)(rows * ld_out * 4), 0x00020000);
-#pragma nounroll
-                for (int q = 0; q < NSL; ++q) {
-                    const int mw = HSPLIT ? (w4 & 1) * 2 + q : w4;      // the M wave whose slot this is
-                    const f32x4 *exr = reinterpret_cast<const f32x4 *>(oreg + (i & 1) * EX_BYTES + mw * 4096);
-                    // stage by stage over all 16 values: written element by element the compiler chains
-                    // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
-                    float zz[16], pp[16];
+                // stage by stage over all 16 values: written element by element the compiler chains
+                // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
+                float zz[16], pp[16];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 z = exr[g * 64 + lane];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 z = exr[g * 64 + lane];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) zz[4 * g + e] = z[e];
-                    }
-                    // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
+                    for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q];
+                }
+                // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
-                    unsigned off = (HSPLIT && q) ? voffs[NSL - 1] : voffs[0];
+                for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
+                unsigned off = voff;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
-                        off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
-                    }
+                for (int e = 0; e < 16; ++e) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
+                    off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
                 }
             }
             if (st) sp[1] = __builtin_amdgcn_s_memtime();
-            if (stage) stage_store((i + 1) & 1);
+            if (stage) stage_store(sreg, (i + 1) & 1);
             if (st) sp[2] = sp[3] = __builtin_amdgcn_s_memtime();
             __syncthreads();
             if (st) sp[4] = __builtin_amdgcn_s_memtime();
+        };
+        if (SDEEP) {
+            // even iteration i: loads tile i+2 into A (tile i, already in LDS, lived there), stores tile i+1 from B
+            for (int i = 0; i < cnt + 2; i += 2) {
+                iteration(i, sregA, sregB);
+                if (i + 1 < cnt + 2) iteration(i + 1, sregB, sregA);
+            }
+        } else {
+            for (int i = 0; i < cnt + 2; ++i) iteration(i, sregA, sregA);
         }
     }
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
@@ -390,7 +385,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
 
 // O_VEC: c % 4 == 0 and O 16-B aligned (compile-time so the scalar fallback's address arithmetic
 // is not hoisted into -- and spilled by -- the vector build)
-template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0, bool HSPLIT = false>
+template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0, bool SDEEP = false>
 __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
     float *__restrict__ out, int64_t ld_out, int xcd_remap) {
@@ -403,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
     const int uwave = __builtin_amdgcn_readfirstlane(wave);     // in an SGPR: role tests are scalar branches
     if (uwave < 4) m_role<KS, STAMP, XP, O_VEC, SIGMOID>(sc, q_packed, stg, oreg, lane, uwave & 3, t & 255);
-    else h_role<KS, SIGMOID, STAMP, XP, HSPLIT>(sc, q_packed, O, out, ld_out, stg, oreg, lane, uwave & 3, t & 255);
+    else h_role<KS, SIGMOID, STAMP, XP, SDEEP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, uwave & 3, t & 255);
 }
 
 }  // namespace rtk_ws
