@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                     } else {
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m == 2 ? al : ah, m == 1 ? Bl[ks] : Bh[ks], acc, 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the gap's pieces BEHIND their MFMA (see rtk_score_ws_kernel.h)
 #pragma unroll
                     for (int pc = g * 32 / GAPS; pc < (g + 1) * 32 / GAPS; ++pc) piece(prev, pc);
                     __builtin_amdgcn_sched_barrier(0);

@@ -219,19 +219,26 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
                         fl[ks % PF] = ll[(ks + PF) * 64 + lane];
                     }
                     // sched_barrier(0) pins the written order: the scheduler otherwise sinks every
-                    // fragment read next to its MFMA (one LDS latency per k-step, 2.4x the chain time)
+                    // fragment read next to its MFMA (one LDS latency per k-step, 2.4x the chain time).
+                    // One barrier on EACH side of every MFMA: with MFMA and gap piece in one region the
+                    // scheduler hoists the piece above the MFMA, which leaves two dependent
+                    // transcendental pieces between one pair of MFMAs and nothing between the next pair
+                    // (the second MFMA then just waits for the pipe): 51 cycles per MFMA instead of ~36.
                     __builtin_amdgcn_sched_barrier(0);
                     if ((3 * ks) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], acc2, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     gap(3 * ks);
                     __builtin_amdgcn_sched_barrier(0);
                     if ((3 * ks + 1) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc2, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (st && ks == KS / 2) sp[4] = __builtin_amdgcn_s_memtime();
                     gap(3 * ks + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if ((3 * ks + 2) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc2, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     gap(3 * ks + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }

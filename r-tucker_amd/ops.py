@@ -359,6 +359,48 @@ def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt):
     return gcore, gR, gS, gO
 
 
+class _GramTN(torch.autograd.Function):
+    """``A^T B`` for tall-skinny fp32 GPU operands ``A (n, p)``, ``B (n, q)``, ``n >> p, q`` -- the Gram-type
+    products of the Riemannian layer (factor Gram matrices in ``T.norm()``, ``U^T M`` in the tangent-space
+    projection; n = 40 943, p = q = 400 at the WN18RR training shape).  rocBLAS runs this shape on
+    ceil(p/256) * ceil(q/256) = 4 workgroups without splitting K (9 ms per product, 70 % of a training step,
+    profiles/r02_train_kernel_stats.csv); here it is the split-K fp32-MFMA GEMM of the C ABI, K cut over
+    the chip and the slabs added in a fixed order (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        lib = _lib.load()
+        A, B = A.contiguous(), B.contiguous()
+        n, p = A.shape
+        q = B.shape[1]
+        dev = A.device
+        C_ = torch.empty((p, q), dtype=torch.float32, device=dev)
+        splits = _splits_for(p, q, n)
+        with torch.cuda.device(dev):
+            skw = torch.empty(max(256, lib.rtk_gemm_f32_splitk_workspace_bytes(p, q, splits)), dtype=torch.uint8, device=dev)
+            _lib.check(lib.rtk_gemm_f32_splitk(A.data_ptr(), 0, p, B.data_ptr(), 0, q, C_.data_ptr(), q, p, q, n, splits,
+                                               skw.data_ptr(), skw.numel(), _stream_ptr(dev)), "rtk_gemm_f32_splitk (A^T B)")
+        ctx.save_for_backward(A, B)
+        return C_
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dA = B @ dC.transpose(0, 1) if ctx.needs_input_grad[0] else None      # (n, q) @ (q, p): n row blocks, fills the chip
+        dB = A @ dC if ctx.needs_input_grad[1] else None
+        return dA, dB
+
+
+def gram_tn(A, B):
+    """``A.T @ B``; tall-skinny fp32 GPU operands go through the split-K HIP GEMM, anything else through torch
+    (the Riemannian layer is generic torch code: float64 CPU tensors in its tests)."""
+    if (A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2
+            and A.shape[0] == B.shape[0] and A.shape[0] >= 8192 and A.shape[0] >= 8 * max(A.shape[1], B.shape[1])
+            and not torch.cuda.is_current_stream_capturing()):
+        return _GramTN.apply(A, B)
+    return A.transpose(0, 1) @ B
+
+
 class _BceLoss1vN(torch.autograd.Function):
     """mean BCE(sigmoid(logits), smoothed multi-hot targets) with the targets given as a CSR."""
 

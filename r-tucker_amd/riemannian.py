@@ -26,7 +26,7 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
-from .tucker import SFTucker, Tucker, _mode_dot, _unfold
+from .tucker import SFTucker, Tucker, _mode_dot, _tn, _unfold
 
 
 def _core_gram(core: torch.Tensor, mode: int) -> torch.Tensor:
@@ -45,7 +45,7 @@ def _solve_right(mat: torch.Tensor, gram: torch.Tensor) -> torch.Tensor:
 
 def _project_out(U: torch.Tensor, M: torch.Tensor) -> torch.Tensor:
     """(I - U U^T) M"""
-    return M - U @ (U.transpose(0, 1) @ M)
+    return M - U @ _tn(U, M)
 
 
 def _block_core(dG: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
@@ -82,13 +82,14 @@ class TuckerTangentVector:
         G = self.point.core
         s = (self.delta_core * self.delta_core).sum()
         for i, d in enumerate(self.delta_factors):
-            s = s + ((d.transpose(0, 1) @ d) * _core_gram(G, i)).sum()
+            s = s + (_tn(d, d) * _core_gram(G, i)).sum()
         return torch.sqrt(torch.clamp(s, min=0.0))
 
     def construct(self) -> Tucker:
         x = self.point
         return Tucker(_block_core(self.delta_core, x.core),
-                      [torch.cat([u, d], dim=1) for u, d in zip(x.factors, self.delta_factors)])
+                      [torch.cat([u, d], dim=1) for u, d in zip(x.factors, self.delta_factors)],
+                      orth_cols=[u.shape[1] for u in x.factors])
 
 
 class TuckerRiemannian:
@@ -114,7 +115,7 @@ class TuckerRiemannian:
         """Orthogonal projection of an explicit Tucker tensor ``Z`` onto the tangent space at ``x``."""
         G = x.core
         Us = x.factors
-        Ms = [u.transpose(0, 1) @ v for u, v in zip(Us, Z.factors)]          # r_i x k_i
+        Ms = [_tn(u, v) for u, v in zip(Us, Z.factors)]          # r_i x k_i
         dG = Z.core
         for i, m in enumerate(Ms):
             dG = _mode_dot(dG, m, i)
@@ -165,9 +166,9 @@ class SFTuckerTangentVector:
         G = self.point.core
         s = (self.delta_core * self.delta_core).sum()
         for i, d in enumerate(self.delta_regular_factors):
-            s = s + ((d.transpose(0, 1) @ d) * _core_gram(G, i)).sum()
+            s = s + (_tn(d, d) * _core_gram(G, i)).sum()
         de = self.delta_shared_factor
-        s = s + ((de.transpose(0, 1) @ de) * self._shared_gram()).sum()
+        s = s + (_tn(de, de) * self._shared_gram()).sum()
         return torch.sqrt(torch.clamp(s, min=0.0))
 
     def construct(self) -> SFTucker:
@@ -175,7 +176,8 @@ class SFTuckerTangentVector:
         assert len(x.regular_factors) == 1 and x.num_shared_factors == 2, "R-TuckER's symmetric model: (R, E, E)"
         return SFTucker(_block_core(self.delta_core, x.core),
                         [torch.cat([u, d], dim=1) for u, d in zip(x.regular_factors, self.delta_regular_factors)],
-                        x.num_shared_factors, torch.cat([x.shared_factor, self.delta_shared_factor], dim=1))
+                        x.num_shared_factors, torch.cat([x.shared_factor, self.delta_shared_factor], dim=1),
+                        orth_cols=[u.shape[1] for u in x.regular_factors] + [x.shared_factor.shape[1]])
 
 
 class SFTuckerRiemannian:
@@ -209,7 +211,7 @@ class SFTuckerRiemannian:
         G = x.core
         nreg, ns = len(x.regular_factors), x.num_shared_factors
         xf, zf = x.factors, Z.factors                        # per-mode lists (shared factor repeated)
-        Ms = [u.transpose(0, 1) @ v for u, v in zip(xf, zf)]
+        Ms = [_tn(u, v) for u, v in zip(xf, zf)]
         dG = Z.core
         for i, m in enumerate(Ms):
             dG = _mode_dot(dG, m, i)

@@ -27,6 +27,12 @@ from typing import Sequence
 import torch
 
 
+def _tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """``A.T @ B`` -- the Gram-type product (tall-skinny on the GPU: split-K HIP GEMM, ``ops.gram_tn``)."""
+    from .ops import gram_tn
+    return gram_tn(A, B)
+
+
 def _mode_dot(core: torch.Tensor, mat: torch.Tensor, mode: int) -> torch.Tensor:
     """core x_mode mat, mat of shape (new, old): contracts axis ``mode`` of the core with mat's columns."""
     return torch.movedim(torch.tensordot(mat, core, dims=([1], [mode])), 0, mode)
@@ -44,12 +50,64 @@ def _gram_norm(core: torch.Tensor, grams: Sequence[torch.Tensor]) -> torch.Tenso
     return torch.sqrt(torch.clamp((t * core).sum(), min=0.0))
 
 
+def _cholesky_qr2(D: torch.Tensor):
+    """Thin QR of a tall-skinny ``D`` by two rounds of Cholesky QR on its Gram matrix (the Gram products are the
+    split-K HIP GEMM on the GPU): O(n k^2) flops in three chip-filling GEMMs instead of k Householder
+    reflections applied one after the other (rocSOLVER's geqrf spends 90 ms on a 40 943 x 400 factor, 55 % of a
+    training step once the Gram products are fixed).  Columns are normalised first (Cholesky QR squares the
+    condition number).  Returns ``None`` when the Gram matrix is numerically singular or the result is not
+    orthonormal to 1e-4 -- the caller then falls back to Householder QR."""
+    scale = torch.linalg.vector_norm(D, dim=0)
+    if not bool((scale > 0).all()):
+        return None
+    Dn = D / scale
+    R_total = None
+    Q = Dn
+    for _ in range(2):
+        S = _tn(Q, Q)
+        L, info = torch.linalg.cholesky_ex(S)
+        if int(info) != 0:
+            return None
+        Q = torch.linalg.solve_triangular(L.transpose(0, 1), Q, upper=True, left=False)      # Q <- Q L^-T
+        R_total = L.transpose(0, 1) if R_total is None else L.transpose(0, 1) @ R_total
+    err = (_tn(Q, Q) - torch.eye(Q.shape[1], dtype=Q.dtype, device=Q.device)).abs().max()
+    if not bool(err < 1e-4):
+        return None
+    return Q, R_total * scale          # D = Q (R diag(scale))
+
+
+def _qr_thin(f: torch.Tensor, n_orth: int = 0):
+    """Thin QR of a factor.  ``n_orth`` > 0: the first ``n_orth`` columns are known to be orthonormal and (up to
+    rounding) orthogonal to the rest -- the ``[U, dU]`` factors of ``TangentVector.construct()`` -- so only the
+    remaining block needs work: ``[U, D] = [U, Q_D] [[I, U^T D], [0, R_D]]``."""
+    n, k = f.shape
+    if n_orth <= 0 or n_orth >= k or not f.is_cuda or f.dtype != torch.float32 or n < 8192:
+        return torch.linalg.qr(f)
+    U, D = f[:, :n_orth], f[:, n_orth:]
+    C = _tn(U, D)                               # ~0 by the gauge condition; removed explicitly
+    D = D - U @ C
+    qr = _cholesky_qr2(D)
+    if qr is None:
+        return torch.linalg.qr(f)
+    Qd, Rd = qr
+    R = f.new_zeros((k, k))
+    R[:n_orth, :n_orth] = torch.eye(n_orth, dtype=f.dtype, device=f.device)
+    R[:n_orth, n_orth:] = C
+    R[n_orth:, n_orth:] = Rd
+    return torch.cat([U, Qd], dim=1), R
+
+
 def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
-    """The r leading left singular vectors of ``mat`` (columns), via the small Gram eigenproblem when the
-    matrix is wide (unfoldings are r x r^2)."""
+    """The r leading left singular vectors of ``mat`` (columns).  Core unfoldings are short and wide (2r x 4r^2):
+    on the GPU in fp32 they come from the eigenvectors of the small Gram matrix ``mat mat^T`` (one GEMM + one
+    2r x 2r symmetric eigenproblem instead of a Jacobi SVD of the wide matrix); the subspace wanted is the
+    dominant one, separated from the rest by the size of the step, so squaring the spectrum costs nothing
+    that matters.  Elsewhere (CPU, float64: the identity tests) the SVD itself."""
     if mat.shape[0] <= r:
         r = mat.shape[0]
-    # SVD of the (small) matrix itself: accuracy matters more than speed here (2r x 4r^2 at most)
+    if mat.is_cuda and mat.dtype == torch.float32 and mat.shape[1] >= 4 * mat.shape[0]:
+        w, V = torch.linalg.eigh(mat @ mat.transpose(0, 1))        # ascending eigenvalues
+        return V[:, -r:].flip(1)
     U, _, _ = torch.linalg.svd(mat, full_matrices=False)
     return U[:, :r]
 
@@ -58,9 +116,12 @@ class Tucker:
     """``X = core x_0 factors[0] x_1 factors[1] x_2 factors[2]`` with factors
     ``[R (nR,a), S (N,b), O (N,c)]`` and core axes (relation, subject, object)."""
 
-    def __init__(self, core: torch.Tensor, factors: Sequence[torch.Tensor]):
+    def __init__(self, core: torch.Tensor, factors: Sequence[torch.Tensor], orth_cols: Sequence[int] = None):
         self.core = core
         self.factors = list(factors)
+        # optional hint for round(): factor i starts with orth_cols[i] orthonormal columns that are orthogonal
+        # to its remaining ones (set by TangentVector.construct(); never required)
+        self.orth_cols = list(orth_cols) if orth_cols is not None else None
 
     @property
     def rank(self):
@@ -71,7 +132,7 @@ class Tucker:
         return tuple(f.shape[0] for f in self.factors)
 
     def norm(self) -> torch.Tensor:
-        return _gram_norm(self.core, [f.transpose(0, 1) @ f for f in self.factors])
+        return _gram_norm(self.core, [_tn(f, f) for f in self.factors])
 
     def full(self) -> torch.Tensor:
         t = self.core
@@ -84,7 +145,7 @@ class Tucker:
         core = self.core
         qs = []
         for i, f in enumerate(self.factors):
-            q, r = torch.linalg.qr(f)                      # thin: (n, k), (k, k)
+            q, r = _qr_thin(f, self.orth_cols[i] if self.orth_cols else 0)    # thin: (n, k), (k, k)
             qs.append(q)
             core = _mode_dot(core, r, i)
         new_factors = []
@@ -112,11 +173,12 @@ class SFTucker:
     (``X = core x_0 R x_1 E x_2 E`` for the symmetric model)."""
 
     def __init__(self, core: torch.Tensor, regular_factors: Sequence[torch.Tensor],
-                 num_shared_factors: int, shared_factor: torch.Tensor):
+                 num_shared_factors: int, shared_factor: torch.Tensor, orth_cols: Sequence[int] = None):
         self.core = core
         self.regular_factors = list(regular_factors)
         self.num_shared_factors = num_shared_factors
         self.shared_factor = shared_factor
+        self.orth_cols = list(orth_cols) if orth_cols is not None else None     # [regular..., shared]; see Tucker
 
     @property
     def rank(self):
@@ -128,8 +190,8 @@ class SFTucker:
         return self.regular_factors + [self.shared_factor] * self.num_shared_factors
 
     def norm(self) -> torch.Tensor:
-        ge = self.shared_factor.transpose(0, 1) @ self.shared_factor
-        grams = [f.transpose(0, 1) @ f for f in self.regular_factors] + [ge] * self.num_shared_factors
+        ge = _tn(self.shared_factor, self.shared_factor)
+        grams = [_tn(f, f) for f in self.regular_factors] + [ge] * self.num_shared_factors
         return _gram_norm(self.core, grams)
 
     def full(self) -> torch.Tensor:
@@ -146,10 +208,10 @@ class SFTucker:
         core = self.core
         qs = []
         for i, f in enumerate(self.regular_factors):
-            q, r = torch.linalg.qr(f)
+            q, r = _qr_thin(f, self.orth_cols[i] if self.orth_cols else 0)
             qs.append(q)
             core = _mode_dot(core, r, i)
-        qe, re = torch.linalg.qr(self.shared_factor)
+        qe, re = _qr_thin(self.shared_factor, self.orth_cols[-1] if self.orth_cols else 0)
         for m in range(nreg, nreg + self.num_shared_factors):
             core = _mode_dot(core, re, m)
         new_regular = []
