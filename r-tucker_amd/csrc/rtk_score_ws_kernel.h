@@ -30,9 +30,20 @@ namespace rtk_ws {
 // ablation build (-DRTK_ABLATE_STAMPS); in the product library every use below is dead code (STAMP = false).
 #ifdef RTK_ABLATE_STAMPS
 __device__ unsigned long long g_ws_stamps[256 * 8 * 8];
+__device__ unsigned long long g_ws_tl[256 * 2 * 64];   // timeline: [workgroup][M wave 0 / H wave 0][event] = code << 56 | s_memtime
 #else
 static constexpr unsigned long long *g_ws_stamps = nullptr;
+static constexpr unsigned long long *g_ws_tl = nullptr;
 #endif
+// timeline event of wave 0 of a role (STAMP builds only): `n` is the role's running event index
+#define RTK_TL(role, code)                                                                                        \
+    do {                                                                                                          \
+        if (STAMP && w4 == 0 && lane == 0 && tl_n < 64) {                                                         \
+            g_ws_tl[(blockIdx.x * 2 + (role)) * 64 + tl_n] =                                                      \
+                ((unsigned long long)(code) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull);      \
+            ++tl_n;                                                                                               \
+        }                                                                                                         \
+    } while (0)
 
 constexpr int EX_BYTES = 4 * 4 * 64 * 16;  // one exchange buffer: 4 M waves x 16 accumulator regs x 64 lanes x f32
 
@@ -109,8 +120,11 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
     const int r = lane & 31, h = lane >> 5, c = sc.c;
     int ntile, mt0, cnt, next_tile;
     bool more;
+    int tl_n = 0;
+    RTK_TL(0, 1);
     while (sc.next(ntile, mt0, cnt, more, next_tile)) {
         __syncthreads();                             // S1: raw O tile visible in LDS
+        RTK_TL(0, 2);
         f16x8 Bh[KS], Bl[KS];
         float us_o;
         static_assert(o_vec, "the launcher only builds the float4 form (c % 4 == 0, aligned O); other shapes run the v3 kernel");
@@ -156,7 +170,9 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
                 }
             }
         }
+        RTK_TL(0, 3);
         __syncthreads();                             // S2: tile mt0 staged, O region free for the exchange
+        RTK_TL(0, 4);
 
         // Fast logistic (SIGMOID == 2) is evaluated HERE, in the shadow of the MFMAs: per value one
         // multiply + v_exp_f32, then one add + v_rcp_f32 (both 1 ulp), a 20-cycle piece in each of the
@@ -257,10 +273,13 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
                 for (int j = 0; j < 32; ++j) gap(j);
             }
             if (st) sp[1] = __builtin_amdgcn_s_memtime();
+            RTK_TL(0, 6);
             __syncthreads();
+            RTK_TL(0, 5);
             if (st) sp[2] = __builtin_amdgcn_s_memtime();
         }
     }
+    RTK_TL(0, 9);
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -311,6 +330,8 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
     };
 
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    int tl_n = 0;
+    RTK_TL(1, 1);
     {
         int first_tile = 0;
         if (sc.peek(first_tile)) load_oraw(first_tile);
@@ -329,11 +350,14 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             const int pc = i * 256 + ht;
             if (pc < 32 * c) reinterpret_cast<u32x4 *>(oreg)[pc] = oraw[i];
         }
+        RTK_TL(1, 2);
         __syncthreads();                             // S1
+        RTK_TL(1, 3);
         stage_store(sregA, 0);
         if (SDEEP && cnt > 1) stage_load(sregB, mt0 + 1);   // tile 1 -> set B (odd tiles live in B, even ones in A)
         if (more) load_oraw(next_tile);              // stays in registers for the whole sweep
         __syncthreads();                             // S2
+        RTK_TL(1, 4);
         if (STAMP && lane == 0 && g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
         // one iteration; `lreg`: the register set this iteration loads into, `sreg`: the set it writes to LDS
@@ -372,9 +396,12 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
                 }
             }
             if (st) sp[1] = __builtin_amdgcn_s_memtime();
+            RTK_TL(1, 6);
             if (stage) stage_store(sreg, (i + 1) & 1);
             if (st) sp[2] = sp[3] = __builtin_amdgcn_s_memtime();
+            RTK_TL(1, 7);
             __syncthreads();
+            RTK_TL(1, 5);
             if (st) sp[4] = __builtin_amdgcn_s_memtime();
         };
         if (SDEEP) {
@@ -387,6 +414,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             for (int i = 0; i < cnt + 2; ++i) iteration(i, sregA, sregA);
         }
     }
+    RTK_TL(1, 9);
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 

@@ -97,6 +97,15 @@ def _qr_thin(f: torch.Tensor, n_orth: int = 0):
     return torch.cat([U, Qd], dim=1), R
 
 
+def _polish(factor: torch.Tensor):
+    """``(Q, R)`` with ``factor = Q R`` and Q orthonormal to fp32 rounding, for a factor that is orthonormal only up
+    to accumulated drift: the structured QR above takes the leading block ``U`` of ``[U, dU]`` as given, so
+    without this the error of the factors would add up step after step.  ``None``: leave the factor alone."""
+    if not factor.is_cuda or factor.dtype != torch.float32 or factor.shape[0] < 8192:
+        return None
+    return _cholesky_qr2(factor)
+
+
 def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
     """The r leading left singular vectors of ``mat`` (columns).  Core unfoldings are short and wide (2r x 4r^2):
     on the GPU in fp32 they come from the eigenvectors of the small Gram matrix ``mat mat^T`` (one GEMM + one
@@ -151,8 +160,13 @@ class Tucker:
         new_factors = []
         for i, q in enumerate(qs):
             u = _truncated_left_basis(_unfold(core, i), int(rank[i]))
-            new_factors.append(q @ u)
+            f = q @ u
             core = _mode_dot(core, u.transpose(0, 1), i)
+            fixed = _polish(f) if self.orth_cols else None
+            if fixed is not None:
+                f, rfix = fixed
+                core = _mode_dot(core, rfix, i)
+            new_factors.append(f)
         return Tucker(core, new_factors)
 
     def __add__(self, other: "Tucker") -> "Tucker":
@@ -217,13 +231,24 @@ class SFTucker:
         new_regular = []
         for i, q in enumerate(qs):
             u = _truncated_left_basis(_unfold(core, i), int(rank[i]))
-            new_regular.append(q @ u)
+            f = q @ u
             core = _mode_dot(core, u.transpose(0, 1), i)
+            fixed = _polish(f) if self.orth_cols else None
+            if fixed is not None:
+                f, rfix = fixed
+                core = _mode_dot(core, rfix, i)
+            new_regular.append(f)
         cat = torch.cat([_unfold(core, m) for m in range(nreg, nreg + self.num_shared_factors)], dim=1)
         ue = _truncated_left_basis(cat, int(rank[nreg]))
         for m in range(nreg, nreg + self.num_shared_factors):
             core = _mode_dot(core, ue.transpose(0, 1), m)
-        return SFTucker(core, new_regular, self.num_shared_factors, qe @ ue)
+        fe = qe @ ue
+        fixed = _polish(fe) if self.orth_cols else None
+        if fixed is not None:
+            fe, rfix = fixed
+            for m in range(nreg, nreg + self.num_shared_factors):
+                core = _mode_dot(core, rfix, m)
+        return SFTucker(core, new_regular, self.num_shared_factors, fe)
 
     def __rmul__(self, scalar) -> "SFTucker":
         return SFTucker(scalar * self.core, list(self.regular_factors), self.num_shared_factors, self.shared_factor)

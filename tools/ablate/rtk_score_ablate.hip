@@ -64,6 +64,15 @@ extern "C" int rtk_ablate_ws_stamps(unsigned long long *host, int n, int clear) 
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rtk_ws::g_ws_stamps), sizeof(unsigned long long) * n);
 }
 
+extern "C" int rtk_ablate_ws_timeline(unsigned long long *host, int n, int clear) {
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(rtk_ws::g_ws_tl)) != hipSuccess) return -1;
+        return (int)hipMemset(p, 0, sizeof(unsigned long long) * 256 * 2 * 64);
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rtk_ws::g_ws_tl), sizeof(unsigned long long) * n);
+}
+
 // ---- two-tiles-per-barrier kernel (rtk_score_ws2_kernel.h), STAMP build
 #include "rtk_score_ws2_kernel.h"
 extern "C" int rtk_ablate_ws2(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld,
