@@ -5,18 +5,18 @@
 
 namespace {
 
-template <int KS, int SG, bool OV, bool HS>
+template <int KS, int SG, bool OV>
 bool launch_v(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld, hipStream_t st) {
     const size_t smem = rtk_ws::lds_bytes<KS>(c);
     static std::atomic<unsigned long long> lds_ok{0};
-    if (rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<KS, SG, OV, false, 0u, HS>), 160 * 1024, lds_ok,
+    if (rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<KS, SG, OV>), 160 * 1024, lds_ok,
                                "score_ws_kernel") != RTK_OK)
         return false;
     // one resident workgroup per CU; the kernel cuts the (entity tile x query tile) space evenly
     const int64_t units = rtk_cdiv(N, 128) * rtk_cdiv(B, 32);
     const unsigned grid = (unsigned)(units < 256 ? units : 256);
     static const int xcd_remap = getenv("RTK_WS_XCD") ? atoi(getenv("RTK_WS_XCD")) : 2;   // A/B: XCD-aware schedule (0 off, 1 both phases, 2 remainder tiles only)
-    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<KS, SG, OV, false, 0u, HS>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld,
+    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<KS, SG, OV>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld,
                        xcd_remap);
     return true;
 }
@@ -25,9 +25,7 @@ template <int KS, int SG>
 bool launch_one(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                 bool o_vec, hipStream_t st) {
     (void)o_vec;
-    static const bool sdeep = getenv("RTK_WS_SDEEP") != nullptr;   // A/B: two query tiles in flight in the helper waves
-    if (sdeep) return launch_v<KS, SG, true, true>(qp, B, O, N, c, out, ld, st);
-    return launch_v<KS, SG, true, false>(qp, B, O, N, c, out, ld, st);   // the caller guarantees o_vec
+    return launch_v<KS, SG, true>(qp, B, O, N, c, out, ld, st);   // the caller guarantees o_vec
 }
 
 template <int KS>

@@ -181,115 +181,113 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
         constexpr bool MSIG = SIGMOID == 2;
         const float kfac = MSIG ? us_o * -1.4426950408889634f : us_o;
         float ee = 0.f;                              // 2^(-z log2 e) of the value in flight
-        f32x16 prev;
-        f32x4 svp[4];                                // row unscale factors of the tile in `prev` (x kfac)
+        // Tile-pipelined form.  Two accumulators that ALTERNATE BETWEEN TILES (not between MFMAs): while the
+        // chain of tile i runs on one of them (a single dependent chain issues a 32x32x16 MFMA every ~35
+        // cycles, tools/ubench/mfma_gap.hip), the gaps turn the OTHER one -- tile i-1, complete since the last
+        // barrier -- into probabilities in place.  Per tile-step this removes the 32 v_mov that zeroed two
+        // accumulators (the first MFMA takes C = 0), the 16 v_add that merged them and the copy into `prev`,
+        // and the row factors are fetched at the start of their own tile's chain instead of behind it; what
+        // is left between two barriers besides the chain is the latency of the first fragment reads.
+        f32x16 accA, accB;
+        f32x4 svA[4], svB[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) prev[e] = 0.f;
+        for (int e = 0; e < 16; ++e) accB[e] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) svp[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < cnt + 2; ++i) {
-            const bool st = STAMP && i == 5 && lane == 0;
-            unsigned long long *sp = g_ws_stamps + (blockIdx.x * 8 + w4) * 8;
-            if (st) sp[0] = __builtin_amdgcn_s_memtime();
+        for (int g = 0; g < 4; ++g) svB[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto iteration = [&](int i, f32x16 &accC, f32x4 (&svC)[4], f32x16 &accP, f32x4 (&svP)[4]) {
             f32x4 *exw = reinterpret_cast<f32x4 *>(oreg + ((i + 1) & 1) * EX_BYTES + w4 * 4096);   // slot of tile i-1
-            // hand-over of tile i-1, one piece per MFMA gap (j = gap index, compile-time after unrolling)
+            const bool chain = i < cnt;
+            // gap j: pieces 0..31 hand tile i-1 over (accP -> probabilities -> exchange slot); 32..35 scale
+            // the row factors of tile i (read from its header at the top of this iteration) by kfac
             auto gap = [&](int j) {
-                if (j >= 32) return;
+                if (j >= 32) {
+                    if (j < 36 && chain) svC[j - 32] = svC[j - 32] * kfac;
+                    return;
+                }
+                if (XP & 4) {                             // (ablation) no logistic: raw accumulators out, once
+                    if (j == 31) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) exw[g * 64 + lane] = f32x4{accP[4 * g], accP[4 * g + 1], accP[4 * g + 2], accP[4 * g + 3]};
+                    }
+                    return;
+                }
                 const int e = j >> 1;
                 if (MSIG) {
                     if (!(j & 1)) {
-                        ee = __builtin_amdgcn_exp2f(prev[e] * svp[e >> 2][e & 3]);
+                        ee = __builtin_amdgcn_exp2f(accP[e] * svP[e >> 2][e & 3]);
                     } else {
-                        prev[e] = __builtin_amdgcn_rcpf(1.0f + ee);
-                        if ((e & 3) == 3) exw[(e >> 2) * 64 + lane] = f32x4{prev[e - 3], prev[e - 2], prev[e - 1], prev[e]};
+                        accP[e] = __builtin_amdgcn_rcpf(1.0f + ee);
+                        if ((e & 3) == 3) exw[(e >> 2) * 64 + lane] = f32x4{accP[e - 3], accP[e - 2], accP[e - 1], accP[e]};
                     }
                 } else if ((j & 7) == 0) {           // logits / exact logistic: unscale only, 4 values per piece
                     const int g = j >> 3;
                     f32x4 z;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) z[q] = prev[4 * g + q] * svp[g][q];
+                    for (int q = 0; q < 4; ++q) z[q] = accP[4 * g + q] * svP[g][q];
                     exw[g * 64 + lane] = z;
                 }
             };
-            if (i < cnt) {
+            if (chain) {
                 const unsigned char *tile = stg + (i & 1) * TILE_BYTES;
                 const f16x8 *lh = reinterpret_cast<const f16x8 *>(tile + RTK_PACK_HDR);
                 const f16x8 *ll = lh + KS * 64;
-                // two accumulators, MFMAs alternating between them: a single dependent chain
-                // issues one 32x32x16 MFMA per ~40 cycles, two independent ones per ~35
-                f32x16 acc, acc2;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = acc2[e] = 0.f;
-                if (st) sp[3] = __builtin_amdgcn_s_memtime();
                 f16x8 fa[PF], fl[PF];                // A fragments PF k-steps ahead
 #pragma unroll
                 for (int p = 0; p < PF; ++p) {
                     fa[p] = lh[p * 64 + lane];
                     fl[p] = ll[p * 64 + lane];
                 }
+                const float *lscale = reinterpret_cast<const float *>(tile);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) svC[g] = *reinterpret_cast<const f32x4 *>(lscale + 8 * g + 4 * h);
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const f16x8 ah = fa[ks % PF], al = fl[ks % PF];
-                    if (ks + PF < KS) {
+                    if (ks + PF < KS && !(XP & 8)) {          // (XP & 8, ablation: the chain re-uses its first fragments)
                         fa[ks % PF] = lh[(ks + PF) * 64 + lane];
                         fl[ks % PF] = ll[(ks + PF) * 64 + lane];
                     }
-                    // sched_barrier(0) pins the written order: the scheduler otherwise sinks every
-                    // fragment read next to its MFMA (one LDS latency per k-step, 2.4x the chain time).
-                    // One barrier on EACH side of every MFMA: with MFMA and gap piece in one region the
-                    // scheduler hoists the piece above the MFMA, which leaves two dependent
-                    // transcendental pieces between one pair of MFMAs and nothing between the next pair
-                    // (the second MFMA then just waits for the pipe): 51 cycles per MFMA instead of ~36.
+                    // sched_barrier(0) pins the written order: the scheduler otherwise sinks every fragment read
+                    // next to its MFMA (one LDS latency per k-step) and hoists a gap's piece above its MFMA (two
+                    // dependent transcendental pieces between one pair of MFMAs, none between the next pair)
                     __builtin_amdgcn_sched_barrier(0);
-                    if ((3 * ks) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], acc2, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], acc, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], ks == 0 ? zero : accC, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     gap(3 * ks);
                     __builtin_amdgcn_sched_barrier(0);
-                    if ((3 * ks + 1) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc2, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], acc, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], accC, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (st && ks == KS / 2) sp[4] = __builtin_amdgcn_s_memtime();
                     gap(3 * ks + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if ((3 * ks + 2) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc2, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], acc, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], accC, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     gap(3 * ks + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (st) sp[5] = __builtin_amdgcn_s_memtime();
 #pragma unroll
-                for (int j = 3 * KS; j < 32; ++j) gap(j);   // short chains: the rest of the hand-over
-                // keep this tile's row factors: its LDS buffer is restaged during the next iteration
-                const float *lscale = reinterpret_cast<const float *>(tile);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) svp[g] = *reinterpret_cast<const f32x4 *>(lscale + 8 * g + 4 * h) * kfac;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) prev[e] = acc[e] + acc2[e];
-                if (st) sp[6] = (unsigned long long)__builtin_amdgcn_s_memtime() + (unsigned long long)(prev[0] == 12345.f);
+                for (int j = 3 * KS; j < 36; ++j) gap(j);   // short chains: the rest of the hand-over, the row factors
             } else if (i == cnt) {                   // drain: hand over the last tile
 #pragma unroll
                 for (int j = 0; j < 32; ++j) gap(j);
             }
-            if (st) sp[1] = __builtin_amdgcn_s_memtime();
             RTK_TL(0, 6);
             __syncthreads();
             RTK_TL(0, 5);
-            if (st) sp[2] = __builtin_amdgcn_s_memtime();
+        };
+        for (int i = 0; i < cnt + 2; i += 2) {
+            iteration(i, accA, svA, accB, svB);
+            if (i + 1 < cnt + 2) iteration(i + 1, accB, svB, accA, svA);
         }
     }
     RTK_TL(0, 9);
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
-// SDEEP: the helpers keep TWO query tiles in flight (tile i+2 is requested while tile i is being multiplied),
-// in two register sets that alternate (the iteration loop is unrolled by two so that each set is a fixed group
-// of registers).  With one tile in flight the L2 round trip of tile i+1 -- queued behind the score stores of
-// the same wave, and a wave's vector-memory operations retire in order -- has to fit into one tile-step.
-// (A/B'd and rejected: splitting the helpers into two staging and two storing waves, so that the storing
-// waves never wait on vmcnt -- 43.3 us against 42.2 us.)
-template <int KS, int SIGMOID, bool STAMP, unsigned XP, bool SDEEP>
+// (A/B'd and rejected, round 2: two staging + two storing helper waves, so that the storing waves never wait on
+// vmcnt -- 43.3 us against 42.2 us; two query tiles in flight in the helpers' registers -- 40.0 against 39.4 us;
+// 16-byte score stores from a transposed read of the exchange slot -- 42.1 against 40.4 us.)
+template <int KS, int SIGMOID, bool STAMP, unsigned XP>
 __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict__ q_packed,
                                        const float *__restrict__ O, float *__restrict__ out, int64_t ld_out,
                                        unsigned char *stg, unsigned char *oreg, int lane, int w4, int ht) {
@@ -299,20 +297,24 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
     constexpr int NOR = 2 * KS;                 // raw O 16-B pieces per helper thread (32*c/256 <= 2*KS)
     const int r = lane & 31, h = lane >> 5, c = sc.c, N = sc.N, B = sc.B;
     u32x4 oraw[NOR];
-    auto load_oraw = [&](int ntile) {   // 128 rows = 32*c pieces of 16 B, contiguous in memory (c % 4 == 0)
+    // pieces [i0, i1) of this lane's share of an O tile (128 rows = 32*c pieces of 16 B, contiguous in memory,
+    // c % 4 == 0); i0 / i1 are compile-time after unrolling
+    auto load_oraw_part = [&](int ntile, int i0, int i1) {
         const int64_t row0 = (int64_t)ntile * 128;
         const int valid = (int)max((int64_t)0, min((int64_t)128, (int64_t)N - row0)) * c;  // floats of real rows
         const float *src = O + row0 * c;
 #pragma unroll
         for (int i = 0; i < NOR; ++i) {
+            if (i < i0 || i >= i1) continue;
             const int pc = i * 256 + ht;
             u32x4 x = {0u, 0u, 0u, 0u};
             if (4 * pc + 4 <= valid) x = *reinterpret_cast<const u32x4 *>(src + 4 * pc);   // valid % 4 == 0
             oraw[i] = x;
         }
     };
-    u32x4 sregA[NLD], sregB[SDEEP ? NLD : 1];
-    auto stage_load = [&](u32x4 *sreg, int mt) {
+    auto load_oraw = [&](int ntile) { load_oraw_part(ntile, 0, NOR); };
+    u32x4 sreg[NLD];
+    auto stage_load = [&](int mt) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(q_packed + (int64_t)mt * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -320,7 +322,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             if (i + 1 < NLD || ch < CHUNKS) sreg[i] = src[ch];
         }
     };
-    auto stage_store = [&](const u32x4 *sreg, int buf) {
+    auto stage_store = [&](int buf) {
         u32x4 *dst = reinterpret_cast<u32x4 *>(stg + buf * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -344,7 +346,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
         // first query tile of the sweep: requested BEFORE the O tile goes to LDS, so its L2 round trip
         // runs beside that write and the S1 wait instead of after them (it took longer than the M
         // waves' conversion and held S2 back)
-        stage_load(sregA, mt0);
+        stage_load(mt0);
 #pragma unroll
         for (int i = 0; i < NOR; ++i) {
             const int pc = i * 256 + ht;
@@ -353,65 +355,69 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
         RTK_TL(1, 2);
         __syncthreads();                             // S1
         RTK_TL(1, 3);
-        stage_store(sregA, 0);
-        if (SDEEP && cnt > 1) stage_load(sregB, mt0 + 1);   // tile 1 -> set B (odd tiles live in B, even ones in A)
-        if (more) load_oraw(next_tile);              // stays in registers for the whole sweep
+        stage_store(0);
         __syncthreads();                             // S2
         RTK_TL(1, 4);
+        // The NEXT O tile stays in registers for the whole sweep.  Its 2*KS loads per lane are NOT issued in one
+        // go: a wave's vector-memory instructions queue in order, so the staging loads and score stores of the
+        // first iterations sat behind 100 KB of prefetch per CU (~8k cycles, with the MFMA waves waiting at S2
+        // or at the first barrier all that time).  They trickle out instead, PFI per iteration, behind that
+        // iteration's own loads and stores; a short sweep issues the rest before its first iteration.
+        constexpr int PFI = 4;
+        const int pf_iters = more ? min(cnt, (NOR + PFI - 1) / PFI) : 0;
+        if (more && pf_iters * PFI < NOR) load_oraw_part(next_tile, pf_iters * PFI, NOR);
         if (STAMP && lane == 0 && g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] == 0) g_ws_stamps[(blockIdx.x * 8 + 4 + w4) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         const unsigned voff = (j < N) ? (unsigned)((4 * h * ld_out + j) * 4) : 0x80000000u;
-        // one iteration; `lreg`: the register set this iteration loads into, `sreg`: the set it writes to LDS
-        auto iteration = [&](int i, u32x4 *lreg, const u32x4 *sreg) {
+        for (int i = 0; i < cnt + 2; ++i) {
             const bool st = STAMP && i == 5 && lane == 0;
             unsigned long long *sp = g_ws_stamps + (blockIdx.x * 8 + 4 + w4) * 8;
             if (st) sp[0] = __builtin_amdgcn_s_memtime();
-            // The staging loads go out first -- in the in-order vmcnt stream they are OLDER than this
-            // iteration's score stores, so the wait at the bottom only covers stores issued a whole iteration
-            // ago (SDEEP: two iterations ago) -- and the LDS writes come last.
-            const bool stage = i + 1 < cnt;                       // tile i+1 goes to LDS at the bottom
-            if (SDEEP ? (i + 2 < cnt) : stage) stage_load(lreg, mt0 + i + (SDEEP ? 2 : 1));
-            if (i >= 2 && !(XP & 2)) {               // scores of tile i-2: logistic + stores
+            // Query tile i+1: its loads go out first -- in the in-order vmcnt stream they are OLDER than
+            // this iteration's score stores, so the wait at the bottom only covers stores issued a whole
+            // iteration ago -- and its LDS writes come last.
+            const bool stage = (i + 1 < cnt) && !(XP & 16);       // (XP & 16, ablation: helpers idle)
+            if (stage) stage_load(mt0 + i + 1);
+            if (i >= 2 && !(XP & 2) && !(XP & 16)) { // scores of tile i-2: logistic + stores
                 const int mt = mt0 + i - 2;
-                const f32x4 *exr = reinterpret_cast<const f32x4 *>(oreg + (i & 1) * EX_BYTES + w4 * 4096);
+                const unsigned char *slot = oreg + (i & 1) * EX_BYTES + w4 * 4096;
                 const int rows = min(32, B - mt * 32);
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     out + (int64_t)mt * 32 * ld_out, 0, (unsigned)(rows * ld_out * 4), 0x00020000);
-                // stage by stage over all 16 values: written element by element the compiler chains
-                // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
-                float zz[16], pp[16];
+                {
+                    const f32x4 *exr = reinterpret_cast<const f32x4 *>(slot);
+                    // stage by stage over all 16 values: written element by element the compiler chains
+                    // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
+                    float zz[16], pp[16];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 z = exr[g * 64 + lane];
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 z = exr[g * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q];
+                        for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q];
+                    }
+                    // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
+                    unsigned off = voff;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
+                        off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                    }
                 }
-                // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
+            }
+            if (i < pf_iters) {                      // this iteration's share of the next O tile
 #pragma unroll
-                for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
-                unsigned off = voff;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
-                    off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
-                }
+                for (int p = 0; p < (NOR + PFI - 1) / PFI; ++p)
+                    if (p == i) load_oraw_part(next_tile, p * PFI, min(NOR, (p + 1) * PFI));
             }
             if (st) sp[1] = __builtin_amdgcn_s_memtime();
             RTK_TL(1, 6);
-            if (stage) stage_store(sreg, (i + 1) & 1);
+            if (stage) stage_store((i + 1) & 1);
             if (st) sp[2] = sp[3] = __builtin_amdgcn_s_memtime();
             RTK_TL(1, 7);
             __syncthreads();
             RTK_TL(1, 5);
             if (st) sp[4] = __builtin_amdgcn_s_memtime();
-        };
-        if (SDEEP) {
-            // even iteration i: loads tile i+2 into A (tile i, already in LDS, lived there), stores tile i+1 from B
-            for (int i = 0; i < cnt + 2; i += 2) {
-                iteration(i, sregA, sregB);
-                if (i + 1 < cnt + 2) iteration(i + 1, sregB, sregA);
-            }
-        } else {
-            for (int i = 0; i < cnt + 2; ++i) iteration(i, sregA, sregA);
         }
     }
     RTK_TL(1, 9);
@@ -420,7 +426,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
 
 // O_VEC: c % 4 == 0 and O 16-B aligned (compile-time so the scalar fallback's address arithmetic
 // is not hoisted into -- and spilled by -- the vector build)
-template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0, bool SDEEP = false>
+template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0>
 __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
     float *__restrict__ out, int64_t ld_out, int xcd_remap) {
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
     const int uwave = __builtin_amdgcn_readfirstlane(wave);     // in an SGPR: role tests are scalar branches
     if (uwave < 4) m_role<KS, STAMP, XP, O_VEC, SIGMOID>(sc, q_packed, stg, oreg, lane, uwave & 3, t & 255);
-    else h_role<KS, SIGMOID, STAMP, XP, SDEEP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, uwave & 3, t & 255);
+    else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, uwave & 3, t & 255);
 }
 
 }  // namespace rtk_ws

@@ -53,6 +53,13 @@ extern "C" int rtk_ablate_ws(const void *qp, int64_t B, int c, const float *O, i
         case 1: return ws_go<1>(qp, B, c, O, N, out, ld, grid, stream);
         case 2: return ws_go<2>(qp, B, c, O, N, out, ld, grid, stream);
         case 3: return ws_go<3>(qp, B, c, O, N, out, ld, grid, stream);
+        case 4: return ws_go<4>(qp, B, c, O, N, out, ld, grid, stream);
+        case 8: return ws_go<8>(qp, B, c, O, N, out, ld, grid, stream);
+        case 12: return ws_go<12>(qp, B, c, O, N, out, ld, grid, stream);
+        case 16: return ws_go<16>(qp, B, c, O, N, out, ld, grid, stream);
+        case 20: return ws_go<20>(qp, B, c, O, N, out, ld, grid, stream);
+        case 24: return ws_go<24>(qp, B, c, O, N, out, ld, grid, stream);
+        case 28: return ws_go<28>(qp, B, c, O, N, out, ld, grid, stream);
     }
     return -5;
 }

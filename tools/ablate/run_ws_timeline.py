@@ -30,7 +30,9 @@ out = torch.empty((B, LD), dtype=torch.float32, device=dev)
 sp = torch.cuda.current_stream().cuda_stream
 _lib.check(lib.rtk_query_vectors_f32(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, S.data_ptr(), n_ent, r.data_ptr(),
                                      h.data_ptr(), B, None, qp.data_ptr(), ws.data_ptr(), ws.numel(), sp), "qv")
-for xp in (0, 2):
+XPS = [int(x) for x in os.environ.get('XPS', '0,2').split(',')]
+BRIEF = os.environ.get('BRIEF') is not None
+for xp in XPS:
     for _ in range(20):       # warm clocks and caches
         assert ab.rtk_ablate_ws(qp.data_ptr(), B, c, O.data_ptr(), n_ent, out.data_ptr(), LD, 256, xp, sp) == 0
     torch.cuda.synchronize()
@@ -46,7 +48,7 @@ for xp in (0, 2):
     tl = tl.reshape(256, 2, 64)
     code = (tl >> np.uint64(56)).astype(np.int64)
     tm = (tl & np.uint64((1 << 56) - 1)).astype(np.int64)
-    print(f"=== xp={xp} (2: helper epilogue off): event time {e0.elapsed_time(e1) * 1e3:.1f} us")
+    print(f"=== xp={xp} (bits: 2 helper epilogue off, 4 no gap work, 8 no A-fragment reads, 16 helpers idle): event time {e0.elapsed_time(e1) * 1e3:.1f} us")
     for role, name in ((0, "M wave 0"), (1, "H wave 0")):
         n_ev = int((code[:, role, :] != 0).sum(axis=1).min())
         t0 = tm[:, role, 0:1]
@@ -55,6 +57,11 @@ for xp in (0, 2):
         p90 = np.percentile(rel, 90, axis=0)
         codes = code[0, role, :n_ev]
         print(f"{name}: {n_ev} events; code: median cycles since start (delta) [p90]")
+        if BRIEF:
+            d = np.diff(med)
+            steady = [d[k - 1] for k in range(1, n_ev) if codes[k] == 6][3:12]
+            print(f"   S1 at {med[1]:.0f}, S2 at {med[3] if role == 0 else med[3]:.0f}, first chain end {med[4]:.0f}; steady chain/epilogue segments {np.round(steady)}; end {med[-1]:.0f}")
+            continue
         prev = 0.0
         for k in range(n_ev):
             print(f"   {k:2d} code {codes[k]}: {med[k]:9.0f} (+{med[k] - prev:7.0f}) [{p90[k]:9.0f}]")
