@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtucker_hip.so")
+# R_TUCKER_AMD_LIB: another build of the same ABI (A/B comparisons of kernel variants on one box)
+LIB_PATH = os.environ.get("R_TUCKER_AMD_LIB") or os.path.join(_HERE, "lib", "librtucker_hip.so")
 
 RTK_OK = 0
 RTK_F32, RTK_BF16 = 0, 1

@@ -134,18 +134,22 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
             // and zeroed by a select), kept in registers for the row maximum and converted from there.
             // (Two passes -- maximum, then conversion -- read the tile twice: the four waves then move
             // 2 x 100 KB through LDS, ~1600 of the tile switch's ~1900 cycles.)
-            const float *lrow = reinterpret_cast<const float *>(oreg) + (w4 * 32 + r) * c;
+            // (the row offset goes through an empty asm: otherwise the 2*KS loop-invariant fragment addresses
+            // are hoisted out of the sweep loop and stay live across the MFMA chains -- 26 VGPRs, spills)
+            int row_off = (w4 * 32 + r) * c, h8 = 8 * h;
+            asm volatile("" : "+v"(row_off), "+v"(h8));
+            const float *lrow = reinterpret_cast<const float *>(oreg) + row_off;
             f32x4 raw[2 * KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int k = 16 * ks + 8 * h;           // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
+                const int k = 16 * ks + h8;              // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
                 raw[2 * ks] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
                 raw[2 * ks + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
             }
             float mx = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int k = 16 * ks + 8 * h;
+                const int k = 16 * ks + h8;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (!(k + 4 <= c)) raw[2 * ks][q] = 0.f;
@@ -312,6 +316,8 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             oraw[i] = x;
         }
     };
+    // (through a buffer descriptor -- one voffset register, no per-piece compare -- the same loads made the
+    // kernel 3 us SLOWER on the same box: 43.2 vs 40.2 us)
     auto load_oraw = [&](int ntile) { load_oraw_part(ntile, 0, NOR); };
     u32x4 sreg[NLD];
     auto stage_load = [&](int mt) {
