@@ -117,6 +117,12 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
+        if args.force_dist and "RANK" not in os.environ:     # one-rank rehearsal started without torchrun
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=3))
 
     import r_tucker_amd as rt  # noqa: F401
