@@ -56,7 +56,7 @@ constexpr int GROUPS_LDS_SLOTS = 2048;   // counters live in LDS up to this many
 // CNT: pointer type of the counters -- an LDS array (ds_add_rtn: ~100 cycles a round) when the slots
 // fit, the workspace otherwise; as one generic pointer the atomics are flat_atomic_* for both and
 // the B = 8192 build took 50 us.
-template <typename CNT>
+template <typename CNT, int NT>
 __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ rel_idx, int B, int n_rel,
                                                   const int32_t *__restrict__ slot_of_rel, int n_slots, int QG,
                                                   CNT cnt, int32_t *__restrict__ order,
@@ -65,23 +65,23 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
                                                   int *sc_q, int *sc_w, int &base_q, int &base_w) {
     const int t = threadIdx.x;
     CNT fill = cnt + n_slots;
-    for (int s = t; s < 2 * n_slots; s += 256) cnt[s] = 0;
+    for (int s = t; s < 2 * n_slots; s += NT) cnt[s] = 0;
     if (t == 0) { base_q = 0; base_w = 0; }
     __syncthreads();
     // (ids are fetched eight at a time ahead of the atomics: one workgroup walks the whole batch,
     // a load per trip would be a chain of B / 256 exposed latencies; 32 at a time costs the HOST
     // kernel 280 registers and its occupancy -- tables 5.5 -> 11 us)
     constexpr int CH = 8;
-    // batches of up to 256 * CH queries: slots and subject ids are read ONCE and kept in registers
+    // batches of up to NT * CH queries: slots and subject ids are read ONCE and kept in registers
     // across the scan (the scatter pass then has no load round trip of its own)
-    const bool single = B <= 256 * CH;
+    const bool single = B <= NT * CH;
     int sl1[CH];
     int64_t hs1[CH];
-    for (int d0 = t; d0 < B; d0 += 256 * CH) {
+    for (int d0 = t; d0 < B; d0 += NT * CH) {
         int sl[CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            const int d = d0 + 256 * k;
+            const int d = d0 + NT * k;
             int64_t r = d < B ? rel_idx[d] : 0;
             r = r < 0 ? 0 : (r >= n_rel ? n_rel - 1 : r);   // bad ids are reported by the contract kernel
             sl[k] = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
@@ -92,15 +92,15 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k)
-            if (d0 + 256 * k < B) atomicAdd(&cnt[sl[k]], 1);
+            if (d0 + NT * k < B) atomicAdd(&cnt[sl[k]], 1);
     }
     __syncthreads();
-    // exclusive scans (queries, work items) over the slots, 256 at a time; fill[] := first position
-    for (int s0 = 0; s0 < n_slots; s0 += 256) {
+    // exclusive scans (queries, work items) over the slots, NT at a time; fill[] := first position
+    for (int s0 = 0; s0 < n_slots; s0 += NT) {
         const int s = s0 + t;
         const int nq = s < n_slots ? cnt[s] : 0;
         const int nw = (nq + QG - 1) / QG;
-        // inclusive scans of (nq, nw) over the 256 slots of this chunk: shuffles inside a wave, the four
+        // inclusive scans of (nq, nw) over the NT slots of this chunk: shuffles inside a wave, the NT / 64
         // wave totals through LDS (two barriers instead of the sixteen of a step-by-step LDS scan)
         int iq = nq, iw = nw;
 #pragma unroll
@@ -126,16 +126,16 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
             }
         }
         __syncthreads();
-        if (t == 255) { base_q += sc_q[255]; base_w += sc_w[255]; }
+        if (t == NT - 1) { base_q += sc_q[NT - 1]; base_w += sc_w[NT - 1]; }
         __syncthreads();
     }
     if (t == 0) flags[2] = (uint32_t)base_w;
-    for (int d0 = t; d0 < B; d0 += 256 * CH) {
+    for (int d0 = t; d0 < B; d0 += NT * CH) {
         int sl[CH];
         int64_t hs[CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            const int d = d0 + 256 * k;
+            const int d = d0 + NT * k;
             if (single) {
                 sl[k] = sl1[k];
                 hs[k] = hs1[k];
@@ -148,7 +148,7 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            const int d = d0 + 256 * k;
+            const int d = d0 + NT * k;
             if (d >= B) continue;
             const int pos = atomicAdd(&fill[sl[k]], 1);
             order[pos] = d;
@@ -160,20 +160,21 @@ __device__ __forceinline__ void build_groups_impl(const int64_t *__restrict__ re
     }
 }
 
+template <int NT>
 __device__ void build_groups(const int64_t *__restrict__ rel_idx, int B, int n_rel,
                              const int32_t *__restrict__ slot_of_rel, int n_slots, int QG,
                              int32_t *__restrict__ cnt_g, int32_t *__restrict__ order,
                              int32_t *__restrict__ work, uint32_t *__restrict__ flags,
                              const int64_t *__restrict__ sub_idx, int64_t *__restrict__ qinfo) {
-    __shared__ int sc_q[256], sc_w[256];
+    __shared__ int sc_q[NT], sc_w[NT];
     __shared__ int base_q, base_w;
     __shared__ int cnt_l[2 * GROUPS_LDS_SLOTS];
     if (n_slots <= GROUPS_LDS_SLOTS)
-        build_groups_impl<int *>(rel_idx, B, n_rel, slot_of_rel, n_slots, QG, (int *)cnt_l, order, work, flags, sub_idx, qinfo,
-                                 sc_q, sc_w, base_q, base_w);
-    else
-        build_groups_impl<int32_t *>(rel_idx, B, n_rel, slot_of_rel, n_slots, QG, cnt_g, order, work, flags, sub_idx, qinfo,
+        build_groups_impl<int *, NT>(rel_idx, B, n_rel, slot_of_rel, n_slots, QG, (int *)cnt_l, order, work, flags, sub_idx, qinfo,
                                      sc_q, sc_w, base_q, base_w);
+    else
+        build_groups_impl<int32_t *, NT>(rel_idx, B, n_rel, slot_of_rel, n_slots, QG, cnt_g, order, work, flags, sub_idx, qinfo,
+                                         sc_q, sc_w, base_q, base_w);
 }
 
 struct GroupArgs {   // by value to the kernels that host the extra block
@@ -186,8 +187,10 @@ struct GroupArgs {   // by value to the kernels that host the extra block
     int64_t *qinfo;
 };
 
-__global__ __launch_bounds__(256) void groups_kernel(GroupArgs ga) {
-    build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
+// on its own: 1024 threads (the build is a chain of dependent round trips per NT * 8 queries; 51 us at B = 8192
+// with 256 threads)
+__global__ __launch_bounds__(1024) void groups_kernel(GroupArgs ga) {
+    build_groups<1024>(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
 }
 
 // -------------------------------------------------------------- tables ------
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void tables_kernel(const T *__restrict__ G, in
     __shared__ float Rs[UT * 64];  // UT relations x a (a <= 64 here)
     const int xb = ga.QG > 0 ? 1 : 0;
     if (xb && blockIdx.x == 0) {   // the extra block (dispatched first): query groups for the contract kernel
-        if (blockIdx.y == 0) build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
+        if (blockIdx.y == 0) build_groups<256>(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
         return;
     }
     const int n_u = n_u_dev ? min(n_u_max, (int)*n_u_dev) : n_u_max;
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256) void transpose_core_kernel(const rtk_bf16 *__r
     if (xb && blockIdx.x == 0) {   // the extra block: query groups for the contract kernel -- block 0, so that it
         // is dispatched first and runs beside the whole transpose (a single workgroup's latency chain,
         // longer than any tile); here, not in the small kernel that packs the relation rows
-        if (blockIdx.y == 0) build_groups(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
+        if (blockIdx.y == 0) build_groups<256>(ga.rel_idx, ga.B, ga.n_rel, ga.slot_of_rel, ga.n_slots, ga.QG, ga.cnt, ga.order, ga.work, ga.flags, ga.sub_idx, ga.qinfo);
         return;
     }
     // 64 (a) x 64 (n) tile through LDS; 8-byte accesses on both sides when the shapes allow (4 elements
@@ -729,7 +732,7 @@ static int build_tables(const T *core, int a, int b, int c, const T *R, int64_t 
         if (rc != RTK_OK) return rc;
     } else {
         // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM (bf16 operands widen on load)
-        if (xb) hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(256), 0, st, ga);
+        if (xb) hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(1024), 0, st, ga);
         int rc = rtk_gemm_f32_ex(R, 1, a, rel_list, core, 0, bc, tables, bc, n_u_max, bc, a, 0, n_u_dev,
                                  sizeof(T) == 2, st);
         if (rc != RTK_OK) return rc;
@@ -804,8 +807,9 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
     }
     const ContractPlan cp = plan_contract(b, c, batch, ws.tables);
     // the slot order is built either way: the per-query kernel uses it to keep a table in one XCD's L2
+    // (the per-position (subject, query, slot) records are only read by the per-query contract kernel)
     GroupArgs ga{rel_idx, planned ? ws.slot_of_rel : nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
-                 (int)batch, (int)n_rel, n_u_max, cp.QG, sub_idx, ws.grp_qinfo};
+                 (int)batch, (int)n_rel, n_u_max, cp.QG, sub_idx, cp.grouped ? nullptr : ws.grp_qinfo};
     int rc = build_tables<T>(core, a, b, c, R, n_rel, planned ? ws.rel_list : nullptr, n_u_max,
                              planned ? ws.flags + 1 : nullptr, ws.tables, ws.core_t, ws.r_packed, ga, st);
     if (rc != RTK_OK) return rc;
@@ -835,8 +839,8 @@ static int from_tables_impl(const float *tables, int64_t n_rel, int b, int c, co
     const bool groups = cp.grouped || order_small;
     if (groups) {
         GroupArgs ga{rel_idx, nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
-                     (int)batch, (int)n_rel, (int)n_rel, cp.QG, sub_idx, ws.grp_qinfo};
-        hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(256), 0, st, ga);
+                     (int)batch, (int)n_rel, (int)n_rel, cp.QG, sub_idx, cp.grouped ? nullptr : ws.grp_qinfo};
+        hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(1024), 0, st, ga);
     }
     return contract_stage<T>(tables, b, c, S, n_sub, rel_idx, sub_idx, n_rel, batch, nullptr, (int)n_rel, cp, groups,
                              ws.grp_work, ws.grp_order, ws.grp_qinfo, ws.flags, v_out, q_packed, st);
