@@ -229,6 +229,25 @@ int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda,
                         float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                         int splits, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same product on the split-fp16 path of the forward (three f16 MFMAs per k-step on hi/lo halves,
+ * fp32 accumulation) for the two B x N sized backward products of asymmetric/R_TuckER.py:47,
+ * dO = dZ^T v and dv = dZ O.  amax_a / amax_b: DEVICE pointers to one float each, an UPPER BOUND of
+ * max|A| and max|B| (for the BCE gradient |dZ| <= |g| / (B N) needs no pass over dZ); each operand is
+ * scaled by the power of two that puts its bound just below 2^15, so an element larger than the bound
+ * overflows to inf (loud), and an element keeps max(2^-22 |x|, 2^-40 bound) of absolute accuracy: the
+ * result is accurate normwise, relative to max|A| max|B| K -- right for a gradient, not for an
+ * orthogonalisation (use rtk_gemm_f32 there).  splits == 1: C may have any ldc >= N, no workspace;
+ * splits > 1: as rtk_gemm_f32_splitk (slabs added in chunk order: deterministic). */
+int rtk_gemm_sf16_splitk(const float *A, int a_kmajor, int64_t lda, const float *amax_a,
+                         const float *B, int b_kmajor, int64_t ldb, const float *amax_b,
+                         float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                         int splits, void *workspace, size_t workspace_bytes, void *stream);
+
+/* max |x| over a rows x cols fp32 matrix with row pitch ld -> *out (one float on the device): the operand
+ * bounds of rtk_gemm_sf16_splitk when the caller has no analytic one.  Order-independent (integer atomicMax
+ * on the bit patterns), NaNs skipped. */
+int rtk_absmax_f32(const float *x, int64_t rows, int64_t cols, int64_t ld, float *out, void *stream);
+
 /*
  * Backward of stage 1 (autograd of asymmetric/R_TuckER.py:43-46, which the Riemannian gradient
  * differentiates through loss_fn, train.py:79-82): given dv = d loss / d v (batch x c, fp32),

@@ -40,6 +40,8 @@ SIGNATURES = {
     "rtk_gemm_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _u, _p]),
     "rtk_gemm_f32_splitk_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "rtk_gemm_f32_splitk": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i64, _i64, _i64, _i64, _i, _p, _sz, _p]),
+    "rtk_gemm_sf16_splitk": (_i, [_p, _i, _i64, _p, _p, _i, _i64, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _sz, _p]),
+    "rtk_absmax_f32": (_i, [_p, _i64, _i64, _i64, _p, _p]),
     "rtk_query_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "rtk_query_vectors_bwd_f32": (_i, [_p, _i, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "rtk_pack_query_vectors": (_i, [_p, _i64, _i, _i, _p, _p]),

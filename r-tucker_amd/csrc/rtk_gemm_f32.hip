@@ -281,6 +281,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 }
 }  // namespace
 
+// C[i] = slabs[0][i] + slabs[1][i] + ... in slab order (shared with rtk_gemm_sf16.hip)
+int rtk_splitk_reduce_launch(const float *slabs, int64_t slab, int splits, float *C, int64_t n, hipStream_t st) {
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) ? n / 4 : 0;
+    const int64_t blocks = n4 > 0 ? rtk_cdiv(n4, 256) : 1;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, slabs,
+                       slab, splits, C, n4, n);
+    return rtk_check_launch("split-K slab reduction");
+}
+
 // Split-K form for short-and-wide products (e.g. dv = dZ . O with K = n_entities): K is cut into
 // `splits` chunks handled by separate workgroups, each writes its partial M x N tile to its own slab
 // of the caller's workspace, and a second kernel adds the slabs in chunk order -- the summation order
@@ -311,12 +320,7 @@ extern "C" int rtk_gemm_f32_splitk(const float *A, int a_kmajor, int64_t lda, co
     int rc = gemm_dispatch<float>(A, a_kmajor, lda, nullptr, B, b_kmajor, ldb, (float *)workspace, ldc, (int)M, (int)N,
                                   (int)K, false, nullptr, st, k_chunk, splits, slab);
     if (rc != RTK_OK) return rc;
-    const int64_t n = M * N;
-    const int64_t n4 = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) ? n / 4 : 0;
-    const int64_t blocks = n4 > 0 ? rtk_cdiv(n4, 256) : 1;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st,
-                       (const float *)workspace, slab, splits, C, n4, n);
-    return rtk_check_launch("rtk_gemm_f32_splitk");
+    return rtk_splitk_reduce_launch((const float *)workspace, slab, splits, C, M * N, st);
 }
 
 namespace {

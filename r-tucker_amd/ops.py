@@ -32,6 +32,9 @@ DEFAULT_SIGMOID = os.environ.get("R_TUCKER_AMD_SIGMOID", "fast")
 # contiguous; R_TUCKER_AMD_ROW_ALIGN=1 restores the dense layout.  The autograd path (training)
 # always uses the dense layout.
 ROW_ALIGN = max(1, int(os.environ.get("R_TUCKER_AMD_ROW_ALIGN", "32")))
+# The two B x N sized backward products (dO = dZ^T v, dv = dZ O): "split_fp16" = three f16 MFMAs per k-step on
+# hi/lo halves like the forward (normwise fp32-class accuracy), "f32" = the exact fp32 MFMA GEMM (5x slower).
+BACKWARD_GEMM = os.environ.get("R_TUCKER_AMD_BWD_GEMM", "split_fp16")
 
 
 def alloc_scores(B, N, device, lead=(), dtype=torch.float32):
@@ -317,11 +320,14 @@ def _splits_for(M, N, K):
     return int(max(1, min(64, 512 // max(tiles, 1), K // 512)))
 
 
-def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt):
+def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt, dz_bound=None):
     """(g_core, g_R, g_S, g_O) from dZ = d loss / d logits (B, N) fp32 and the saved fp32 query vectors,
     all in HIP kernels with a fixed summation order (bit-identical from run to run): dO = dZ^T v and
-    dv = dZ O on the fp32 MFMA GEMM (split-K slabs added in chunk order), then the stage-1 backward
-    ``rtk_query_vectors_bwd_f32`` (two more GEMMs and a deterministic row scatter)."""
+    dv = dZ O (split-K slabs added in chunk order) on the split-fp16 MFMA path of the forward
+    (``BACKWARD_GEMM = "f32"`` / ``R_TUCKER_AMD_BWD_GEMM=f32``: the exact fp32 MFMA GEMM), then the stage-1
+    backward ``rtk_query_vectors_bwd_f32`` (two more GEMMs and a deterministic row scatter).  ``dz_bound``: a
+    one-element device tensor >= max|dZ| when the caller knows one (the BCE gradient does); otherwise one
+    max-reduction over dZ finds it."""
     lib = _lib.load()
     dev = dZ.device
     B, N = dZ.shape
@@ -329,20 +335,43 @@ def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt):
     a, b, c = core.shape
     core, R, S, Of = core.contiguous(), R.contiguous(), S.contiguous(), O.contiguous()
     gO = gcore = gR = gS = None
+    sf16 = BACKWARD_GEMM != "f32"
     with torch.cuda.device(dev):
         sp = _stream_ptr(dev)
+        if sf16:
+            bounds = torch.empty(3, dtype=torch.float32, device=dev)      # max|dZ|, max|v|, max|O|
+
+            def absmax(x, ld, slot):
+                _lib.check(lib.rtk_absmax_f32(x.data_ptr(), x.shape[0], x.shape[1], ld, bounds[slot:].data_ptr(), sp),
+                           "rtk_absmax_f32")
+                return bounds[slot:slot + 1]
+            if dz_bound is None:
+                dz_bound = absmax(dZ, ldz, 0)
+            dz_bound = dz_bound.to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+            v_bound = absmax(v, c, 1)
         if needs[3]:
             # gO[j, k] = sum_d dZ[d, j] * v[d, k]   -- fp32 MFMA GEMM, both operands M-major
             gO = torch.empty((N, c), dtype=torch.float32, device=dev)
-            _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, ldz, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
-                       "rtk_gemm_f32 (dO)")
+            if sf16:
+                _lib.check(lib.rtk_gemm_sf16_splitk(dZ.data_ptr(), 0, ldz, dz_bound.data_ptr(), v.data_ptr(), 0, c,
+                                                    v_bound.data_ptr(), gO.data_ptr(), c, N, c, B, 1, None, 0, sp),
+                           "rtk_gemm_sf16_splitk (dO)")
+            else:
+                _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, ldz, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
+                           "rtk_gemm_f32 (dO)")
         if needs[0] or needs[1] or needs[2]:
             # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K, slabs reduced in chunk order
             dv = torch.empty((B, c), dtype=torch.float32, device=dev)
             splits = _splits_for(B, c, N)
             skw = torch.empty(max(256, lib.rtk_gemm_f32_splitk_workspace_bytes(B, c, splits)), dtype=torch.uint8, device=dev)
-            _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, ldz, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
-                                               splits, skw.data_ptr(), skw.numel(), sp), "rtk_gemm_f32_splitk (dv)")
+            if sf16:
+                o_bound = absmax(Of, c, 2)
+                _lib.check(lib.rtk_gemm_sf16_splitk(dZ.data_ptr(), 1, ldz, dz_bound.data_ptr(), Of.data_ptr(), 0, c,
+                                                    o_bound.data_ptr(), dv.data_ptr(), c, B, c, N, splits, skw.data_ptr(),
+                                                    skw.numel(), sp), "rtk_gemm_sf16_splitk (dv)")
+            else:
+                _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, ldz, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
+                                                   splits, skw.data_ptr(), skw.numel(), sp), "rtk_gemm_f32_splitk (dv)")
             gcore = torch.empty_like(core) if needs[0] else None
             gR = torch.empty_like(R) if needs[1] else None
             gS = torch.empty_like(S) if needs[2] else None
@@ -439,7 +468,9 @@ class _BceLoss1vN(torch.autograd.Function):
             _lib.check(lib.rtk_bce_grad_f32(P.data_ptr(), B, N, P.stride(0), pair_slot.data_ptr(), pair_ptr.data_ptr(),
                                             pair_obj.data_ptr(), ctx.eps, g.data_ptr(), 1.0 / (B * N), _stream_ptr(dev)),
                        "rtk_bce_grad_f32")
-        return _grads_from_dZ(core, R, S, O, h, r, v, P, ctx.needs_input_grad, pdt) + (None,) * 6
+        # |dZ| = |P - y| |g| / (B N) <= |g| / (B N): the operand bound of the split-fp16 GEMMs, no pass over dZ
+        return _grads_from_dZ(core, R, S, O, h, r, v, P, ctx.needs_input_grad, pdt,
+                              dz_bound=g.abs() * (1.0 / (B * N))) + (None,) * 6
 
 
 def bce_loss_1vN(core, R, S, O, subject_idx, relation_idx, flt, item_ids, label_smoothing=0.0):

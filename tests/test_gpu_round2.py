@@ -258,6 +258,89 @@ def test_training_shape_gradients_against_reference_fixture(rt, golden, golden_m
     assert int((g_S.abs().sum(dim=1) > 0).sum()) == int(g["g_S_nonzero_rows"])
 
 
+@pytest.mark.parametrize("M,N,K,ak,bk,splits,mag", [
+    (300, 400, 777, 0, 0, 1, 1.0),        # dO-like: both operands M-major, ragged everything
+    (512, 400, 20011, 1, 0, 7, 1.0),      # dv-like: A K-major, split over K
+    (130, 70, 515, 1, 1, 3, 1.0),
+    (96, 40, 65, 1, 0, 4, 1.0),           # chunks of 32: the fourth starts past K (writes its zero slab only)
+    (64, 33, 100, 0, 1, 1, 1.0),
+    (257, 129, 1000, 0, 0, 4, 3e-9),      # magnitudes of a BCE gradient: nothing survives in fp16 without the scale
+    (100, 100, 64, 1, 0, 1, 1e20),
+])
+def test_gemm_split_fp16_against_float64(rt, M, N, K, ak, bk, splits, mag):
+    """rtk_gemm_sf16_splitk (the backward products' GEMM): all operand layouts, ragged tiles, split-K, operand
+    magnitudes far outside fp16's range.  Error bound: each element keeps max(2^-22 |x|, 2^-40 bound) of
+    absolute accuracy, so |dC| <= ~2^-21 sum_k |a||b| + K 2^-39 amax_a amax_b; checked at 2^-19 of that form."""
+    lib = rt._lib.load()
+    rng = np.random.default_rng(M * 7 + N)
+    A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 0, (M, K)))).astype(np.float32) * np.float32(mag)
+    Bm = (rng.standard_normal((N, K)) * np.exp(rng.uniform(-6, 0, (N, K)))).astype(np.float32)
+    dA = torch.from_numpy(A if ak else np.ascontiguousarray(A.T)).cuda()
+    dB = torch.from_numpy(Bm if bk else np.ascontiguousarray(Bm.T)).cuda()
+    lda, ldb = (K if ak else M), (K if bk else N)
+    # a loose bound (3x the true maximum) must do: the caller of the BCE gradient only knows |dZ| <= |g| / (B N)
+    ba = torch.tensor([3.0 * np.abs(A).max()], dtype=torch.float32, device="cuda")
+    bb = torch.tensor([np.abs(Bm).max()], dtype=torch.float32, device="cuda")
+    ldc = N if splits > 1 else N + 3
+    C = torch.full((M, ldc), 7.0, dtype=torch.float32, device="cuda")
+    ws = torch.empty(max(256, lib.rtk_gemm_f32_splitk_workspace_bytes(M, N, splits)), dtype=torch.uint8, device="cuda")
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def run(out):
+        return lib.rtk_gemm_sf16_splitk(dA.data_ptr(), ak, lda, ba.data_ptr(), dB.data_ptr(), bk, ldb, bb.data_ptr(),
+                                        out.data_ptr(), ldc, M, N, K, splits, ws.data_ptr(), ws.numel(), sp)
+    assert run(C) == 0, lib.rtk_last_error_string()
+    ref = A.astype(np.float64) @ Bm.astype(np.float64).T
+    got = C[:, :N].cpu().double().numpy()
+    bound = 2.0 ** -19 * (np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64).T) \
+        + K * 2.0 ** -37 * float(ba.item()) * float(bb.item())
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got - ref) / bound) <= 1.0
+    assert np.abs(got - ref).max() <= 3e-6 * np.abs(ref).max()
+    if ldc > N:
+        assert (C[:, N:] == 7.0).all()          # nothing written past the row
+    C2 = torch.full_like(C, 7.0)
+    assert run(C2) == 0 and torch.equal(C, C2)  # fixed summation order
+    if splits > 1:
+        assert lib.rtk_gemm_sf16_splitk(dA.data_ptr(), ak, lda, ba.data_ptr(), dB.data_ptr(), bk, ldb, bb.data_ptr(),
+                                        C2.data_ptr(), ldc, M, N, K, splits, ws.data_ptr(), 16, sp) == -2
+
+
+def test_absmax(rt):
+    """rtk_absmax_f32: strided rows (the padding of a score buffer is not read), odd sizes, NaNs skipped, zeros."""
+    lib = rt._lib.load()
+    sp = torch.cuda.current_stream().cuda_stream
+    out = torch.full((1,), 7.0, device="cuda")
+    for rows, cols, ld in ((1, 1, 1), (3, 5, 8), (512, 4099, 4128), (40943, 400, 400), (7, 1000, 1000)):
+        buf = torch.randn(rows, ld, device="cuda")
+        buf[:, cols:] = 1e30                                  # padding: must be ignored
+        buf[rows // 2, cols // 2] = -123.5
+        assert lib.rtk_absmax_f32(buf.data_ptr(), rows, cols, ld, out.data_ptr(), sp) == 0
+        assert out.item() == buf[:, :cols].abs().max().item() == 123.5
+    z = torch.zeros(4, 4, device="cuda")
+    z[1, 1] = float("nan")
+    assert lib.rtk_absmax_f32(z.data_ptr(), 4, 4, 4, out.data_ptr(), sp) == 0 and out.item() == 0.0
+
+
+def test_backward_gemm_modes_agree(rt):
+    """The split-fp16 backward products against the exact fp32 MFMA GEMM on the same dZ: normwise 1e-5."""
+    n_ent, n_rel, B, rank = 9001, 7, 200, (5, 96, 96)
+    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 21)
+    h, r = gen.make_queries(n_ent, n_rel, B, 21)
+    w = torch.from_numpy(np.random.default_rng(2).standard_normal((B, n_ent)).astype(np.float32)).cuda()
+    out = {}
+    for mode in ("split_fp16", "f32"):
+        rt.ops.BACKWARD_GEMM = mode
+        try:
+            leaves = [torch.from_numpy(x).cuda().requires_grad_(True) for x in (core, R, S, O)]
+            (rt.score_1vN(*leaves, torch.from_numpy(h).cuda(), torch.from_numpy(r).cuda()) * w).sum().backward()
+            out[mode] = [x.grad.clone() for x in leaves]
+        finally:
+            rt.ops.BACKWARD_GEMM = "split_fp16"
+    for g0, g1 in zip(out["split_fp16"], out["f32"]):
+        assert (g0 - g1).abs().max().item() <= 1e-5 * g1.abs().max().item()
+
+
 # ------------------------------------------------------------------ BASELINE configs[2], [3] --------
 def test_c3_full_size_sym_bf16(rt):
     """BASELINE configs[2] at FULL size: FB15k-237 shape, symmetric, rank (200,200,200), B = 2048, bf16 --
