@@ -1,6 +1,8 @@
 """Epoch-wise schedules of the ``||T||^2`` coefficient (``train.py:139``: ``regularization_coeff =
-regulizer.step()`` once per epoch) -- same class names and constructor arguments as
-``src/utils/regularization.py``, written as closed-form functions of the step count.
+regulizer.step()`` once per epoch) -- the class names, constructor arguments and attributes (``val``,
+``cur_step``, ``base_val``, ``final_val``, ``num_steps``, ``strategy``) of ``src/utils/regularization.py``
+on ONE schedule implementation: a policy is a direction (down / up / down-and-restart) plus a rule from
+``RULES`` that moves the value by one step.
 
 Behaviour kept: ``step()`` first counts, returns the CURRENT value once it has reached the final value
 and otherwise moves it one step and returns the new value (so "exp" 1e-4 -> 3e-9 in 350 steps overshoots
@@ -11,66 +13,52 @@ from __future__ import annotations
 
 import math
 
+# rule(policy, k) -> value after the k-th move (k = 1, 2, ...)
+RULES = {
+    "linear": lambda p, k: p.val + (p.final_val - p.base_val) / p.num_steps,
+    "exp": lambda p, k: p.val * math.pow(p.final_val / p.base_val, 1.0 / p.num_steps),
+    "cos": lambda p, k: p.final_val + (p.base_val - p.final_val) * (1 + math.cos(math.pi * min(k, p.num_steps) / p.num_steps)) / 2,
+    "const": lambda p, k: p.val,
+}
+
 
 class RegularizationCoeffPolicy:
-    def __init__(self, base_val, num_steps):
-        self.base_val, self.num_steps = base_val, num_steps
-        self.val = base_val
-        self.cur_step = 0
+    """Constant coefficient; the base of every schedule."""
+    direction = 0                      # -1: towards a smaller final value, +1: towards a larger one
+    allowed = ()                       # rule names this policy accepts
+    unsupported = "This policy is not supported"
+
+    def __init__(self, base_val, num_steps, final_val=None, strategy="linear"):
+        self.base_val = self.val = base_val
+        self.num_steps, self.final_val, self.strategy = num_steps, final_val, strategy
+        self.cur_step = self._moves = 0
+        if self.direction and strategy not in self.allowed:
+            raise NotImplementedError(self.unsupported)
+
+    def _arrived(self):
+        return not self.direction or (self.val - self.final_val) * self.direction >= 0
 
     def step(self):
         self.cur_step += 1
+        if not self._arrived():
+            self._moves += 1
+            self.val = RULES[self.strategy](self, self._moves)
         return self.val
 
 
 class IntervalPolicy(RegularizationCoeffPolicy):
-    def __init__(self, base_val, num_steps, final_val):
-        super().__init__(base_val, num_steps)
-        self.final_val = final_val
+    """A schedule between two values (abstract: no direction)."""
 
 
 class SimpleDecreasingPolicy(IntervalPolicy):
-    STRATEGIES = ("linear", "exp", "cos", "const")
-
-    def __init__(self, base_val, num_steps, final_val, strategy="linear"):
-        super().__init__(base_val, num_steps, final_val)
-        if strategy not in self.STRATEGIES:
-            raise NotImplementedError("This decreasing policy is not supported")
-        self.strategy = strategy
-        self._moves = 0          # how many times the value has been moved
-
-    def _next(self):
-        k = self._moves + 1
-        if self.strategy == "linear":
-            return self.val - (self.base_val - self.final_val) / self.num_steps
-        if self.strategy == "exp":
-            return self.val * math.pow(self.final_val / self.base_val, 1.0 / self.num_steps)
-        if self.strategy == "cos":
-            return self.final_val + (self.base_val - self.final_val) * (1 + math.cos(math.pi * min(k, self.num_steps) / self.num_steps)) / 2
-        return self.val          # const
-
-    def step(self):
-        self.cur_step += 1
-        if self.val <= self.final_val:
-            return self.val
-        self.val = self._next()
-        self._moves += 1
-        return self.val
+    direction, allowed = -1, tuple(RULES)
+    unsupported = "This decreasing policy is not supported"
+    STRATEGIES = allowed
 
 
 class SimpleIncreasingPolicy(IntervalPolicy):
-    def __init__(self, base_val, num_steps, final_val, strategy="linear"):
-        super().__init__(base_val, num_steps, final_val)
-        if strategy != "linear":
-            raise NotImplementedError("This increasing policy is not supported")
-        self.strategy = strategy
-        self.step_size = (final_val - base_val) / num_steps
-
-    def step(self):
-        self.cur_step += 1
-        if self.val < self.final_val:
-            self.val += self.step_size
-        return self.val
+    direction, allowed = +1, ("linear",)
+    unsupported = "This increasing policy is not supported"
 
 
 class CyclicDecreasingPolicy(SimpleDecreasingPolicy):
@@ -78,6 +66,6 @@ class CyclicDecreasingPolicy(SimpleDecreasingPolicy):
 
     def step(self):
         val = super().step()
-        if val <= self.final_val:
+        if self._arrived():
             self.val, self.cur_step, self._moves = self.base_val, 0, 0
         return val
