@@ -62,7 +62,11 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(const float *__restrict__
 // Workgroups [0, B): subject rows -> gS;  [B, 2B): relation rows -> gR.  A workgroup whose query is
 // not the first with its id exits; the first one sums the rows of all queries with that id, in
 // increasing query order, and writes the destination row (the rest of the matrix was zeroed).
-constexpr int SC_CB = 4;   // column blocks of 256 held in registers: row width <= 1024
+// The ids of the batch are copied to LDS once (B <= SC_IDS): the duplicate check and the match lists then
+// cost no memory round trip -- read from global memory at every step the kernel was a chain of ~8 dependent
+// latencies (34 us for 512 rows).
+constexpr int SC_CB = 4;      // column blocks of 256 held in registers: row width <= 1024
+constexpr int SC_IDS = 8192;  // ids kept in LDS (32 KB); larger batches read them from global memory
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t *__restrict__ sub_idx,
                                                            const float *__restrict__ rows_S, int b,
                                                            float *__restrict__ gS, int64_t n_sub,
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t *__rest
                                                            float *__restrict__ gR, int64_t n_rel, int B) {
     __shared__ unsigned long long masks[4];
     __shared__ int lst[256];
+    __shared__ int sid[SC_IDS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool rel = (int)blockIdx.x >= B;
     const int d = rel ? blockIdx.x - B : blockIdx.x;
@@ -78,11 +83,17 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t *__rest
     const float *rows = rel ? rows_R : rows_S;
     float *dst = rel ? gR : gS;
     const int w = rel ? a : b;
-    const int64_t n = rel ? n_rel : n_sub;
+    const int64_t n = rel ? n_rel : n_sub;        // < 2^31 (host)
     if (!dst) return;
-    const int64_t my = clamp_id(ids[d], n);
+    const bool in_lds = B <= SC_IDS;
+    if (in_lds) {
+        for (int i = t; i < B; i += 256) sid[i] = (int)clamp_id(ids[i], n);
+        __syncthreads();
+    }
+    auto id_at = [&](int i) -> int { return in_lds ? sid[i] : (int)clamp_id(ids[i], n); };
+    const int my = id_at(d);
     int dup = 0;
-    for (int i = t; i < d; i += 256) dup |= (clamp_id(ids[i], n) == my);
+    for (int i = t; i < d; i += 256) dup |= (id_at(i) == my);
     if (__syncthreads_or(dup)) return;
     float acc[SC_CB];
 #pragma unroll
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t *__rest
     for (int base = d; base < B; base += 256) {
         // the queries of this block of 256 that carry the id, compacted in query order into lst[]
         const int i = base + t;
-        const bool m = i < B && clamp_id(ids[i], n) == my;
+        const bool m = i < B && id_at(i) == my;
         const unsigned long long bal = __ballot(m);
         if (lane == 0) masks[wave] = bal;
         __syncthreads();
@@ -103,8 +114,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t *__rest
         }
         if (m) lst[before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
         __syncthreads();
-        // rows added in list (= query) order; the loads of eight rows are in flight together (one at a time this
-        // was a chain of dependent memory latencies: 48 us at the WN18RR shape, where a relation has ~23 queries)
+        // rows added in list (= query) order; the loads of eight rows are in flight together
         for (int j0 = 0; j0 < count; j0 += 8) {
             float x[8][SC_CB];
 #pragma unroll
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t *__rest
     }
 #pragma unroll
     for (int k = 0; k < SC_CB; ++k)
-        if (k * 256 + t < w) dst[my * w + k * 256 + t] = acc[k];
+        if (k * 256 + t < w) dst[(int64_t)my * w + k * 256 + t] = acc[k];
 }
 
 struct BwdWs {
@@ -179,6 +189,7 @@ extern "C" int rtk_query_vectors_bwd_f32(const float *core, int a, int b, int c,
     RTK_REQUIRE(core && R && S && rel_idx && sub_idx && dv, RTK_ERR_BAD_ARG, "%s: null operand", fn);
     RTK_REQUIRE(a > 0 && b > 0 && c > 0 && n_rel > 0 && n_sub > 0 && batch > 0, RTK_ERR_BAD_ARG, "%s: sizes must be positive", fn);
     RTK_REQUIRE(batch < (1ll << 30), RTK_ERR_UNSUPPORTED, "%s: batch too large", fn);
+    RTK_REQUIRE(n_rel < (1ll << 31) && n_sub < (1ll << 31), RTK_ERR_UNSUPPORTED, "%s: more than 2^31-1 rows", fn);
     RTK_REQUIRE(a <= 256 * SC_CB && b <= 256 * SC_CB, RTK_ERR_UNSUPPORTED, "%s: rank above %d not supported (a=%d b=%d)", fn, 256 * SC_CB, a, b);
     RTK_REQUIRE((size_t)(a + b) * 4 <= 64 * 1024, RTK_ERR_UNSUPPORTED, "%s: a + b too large for LDS", fn);
     const size_t need = rtk_query_bwd_workspace_bytes(batch, a, b, c);

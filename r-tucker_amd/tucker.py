@@ -115,8 +115,17 @@ def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
     if mat.shape[0] <= r:
         r = mat.shape[0]
     if mat.is_cuda and mat.dtype == torch.float32 and mat.shape[1] >= 4 * mat.shape[0]:
-        w, V = torch.linalg.eigh(mat @ mat.transpose(0, 1))        # ascending eigenvalues
-        return V[:, -r:].flip(1)
+        gram = mat @ mat.transpose(0, 1)
+        # rocSOLVER's divide-and-conquer gives up on Gram matrices whose small eigenvalues are rounding noise
+        # (a small step leaves the new directions 1e-4 of the old ones: 1e-8 after squaring): retry in
+        # float64, then fall back to the SVD of the unfolding itself
+        for g in (gram, gram.double()):
+            try:
+                w, V = torch.linalg.eigh(g)                        # ascending eigenvalues
+            except torch.linalg.LinAlgError:
+                continue
+            if torch.isfinite(V).all():
+                return V[:, -r:].flip(1).to(mat.dtype)
     U, _, _ = torch.linalg.svd(mat, full_matrices=False)
     return U[:, :r]
 
