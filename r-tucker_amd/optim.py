@@ -16,6 +16,7 @@ parameters' device.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Union
 
 import torch
@@ -31,6 +32,32 @@ def _bump(p: torch.Tensor) -> None:
     inc = getattr(torch.autograd.graph, "increment_version", None)
     if inc is not None:
         inc(p)
+
+
+CHECK_FINITE = os.environ.get("R_TUCKER_AMD_CHECK_FINITE", "0") == "1"
+
+
+def _check_finite(what, vec_or_tensor):
+    """Debugging aid (``R_TUCKER_AMD_CHECK_FINITE=1``; one device sync per call): name the first non-finite
+    piece of a tangent vector / container / tensor instead of failing later inside a factorisation."""
+    if not CHECK_FINITE:
+        return
+    pieces = {}
+    for name in ("delta_core", "delta_factors", "delta_regular_factors", "delta_shared_factor", "core", "factors",
+                 "regular_factors", "shared_factor"):
+        v = getattr(vec_or_tensor, name, None)
+        if v is not None:
+            pieces[name] = v
+    if torch.is_tensor(vec_or_tensor):
+        pieces = {"tensor": vec_or_tensor}
+    for name, v in pieces.items():
+        for i, t in enumerate(v if isinstance(v, (list, tuple)) else [v]):
+            if not torch.isfinite(t).all():
+                where = (~torch.isfinite(t)).nonzero()
+                lo, hi = where.min(dim=0).values.tolist(), where.max(dim=0).values.tolist()
+                raise FloatingPointError(f"{what}: {name}[{i}] of shape {tuple(t.shape)} has {where.shape[0]} non-finite "
+                                         f"entries, index range {lo} .. {hi}, first {where[:4].tolist()}, "
+                                         f"values {t[tuple(where[0].tolist())].item()}")
 
 
 class _ManifoldOptimizer(Optimizer):
@@ -61,8 +88,14 @@ class _ManifoldOptimizer(Optimizer):
     def _retract_and_write(self):
         lr = self.param_groups[0]["lr"]
         x_k = self.direction.point
+        _check_finite("direction before the step", self.direction)
+        _check_finite("point before the step", x_k)
         moved = (-lr) * self.direction + self.geometry.TangentVector(x_k)
-        x_new = moved.construct().round(self.rank)
+        _check_finite("moved tangent vector", moved)
+        built = moved.construct()
+        _check_finite("constructed point x - lr d", built)
+        x_new = built.round(self.rank)
+        _check_finite("rounded point", x_new)
         params = self.param_groups[0]["params"]
         if self.symmetric:
             W, E, R = params
@@ -108,8 +141,12 @@ class RSGDwithMomentum(_ManifoldOptimizer):
             self.momentum = geo.project(x_k, self.direction)
         else:
             self.momentum = geo.TangentVector(x_k, torch.zeros_like(x_k.core))
+        _check_finite("momentum projected to the new point", self.momentum)
         rgrad, self.loss = geo.grad(loss_fn, x_k)
+        _check_finite("loss", self.loss)
+        _check_finite("Riemannian gradient", rgrad)
         rgrad_norm = rgrad.norm().detach()
+        _check_finite("gradient norm", rgrad_norm)
         self.direction = self._normalised(rgrad, rgrad_norm, normalize_grad) + self.momentum_beta * self.momentum
         return rgrad_norm
 

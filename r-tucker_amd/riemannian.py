@@ -29,18 +29,31 @@ import torch
 from .tucker import SFTucker, Tucker, _mode_dot, _tn, _unfold
 
 
-def _core_gram(core: torch.Tensor, mode: int) -> torch.Tensor:
+def _core_gram(core: torch.Tensor, mode: int, wide: bool = False) -> torch.Tensor:
+    """``G_(mode) G_(mode)^T``.  ``wide``: accumulate an fp32 core's Gram matrix in float64 (the products are
+    exact, so eigenvalues down to 1e-14 of the largest survive instead of 1e-7) -- for the inverse below."""
     u = _unfold(core, mode)
+    if wide and u.dtype == torch.float32:
+        u = u.double()
     return u @ u.transpose(0, 1)
 
 
+# Eigenvalues of the core Gram matrix below RCOND * largest count as zero in ``_solve_right``: singular values
+# of the core unfolding below 1e-4 of the largest.
+RCOND = 1e-8
+
+
 def _solve_right(mat: torch.Tensor, gram: torch.Tensor) -> torch.Tensor:
-    """mat @ gram^-1 for a symmetric positive (semi)definite ``gram`` (least-squares pseudo-inverse when
-    the core unfolding is rank-deficient, e.g. a zero core at initialisation)."""
-    try:
-        return torch.linalg.solve(gram, mat.transpose(0, 1)).transpose(0, 1)
-    except RuntimeError:      # singular
-        return mat @ torch.linalg.pinv(gram)
+    """``mat @ gram^+`` for the symmetric positive semidefinite core Gram matrix, as a TRUNCATED pseudo-inverse
+    (in ``gram``'s precision; the result in ``mat``'s).  The gauge-fixed factor components of a tangent vector
+    carry the inverse of the core's Gram matrix; a core unfolding that has lost a direction numerically (seen
+    after ~1400 small steps on WN18RR: one singular value of the mode-1 unfolding collapsed) made the plain
+    solve return entries of 1e37 in one column, finite until multiplied by the learning rate.  A direction the
+    core does not use has no tangent component of its own -- the core component ``dG`` still moves it."""
+    w, V = torch.linalg.eigh(gram)
+    keep = w > RCOND * w[-1].clamp_min(0)
+    winv = torch.where(keep, 1.0 / torch.where(keep, w, torch.ones_like(w)), torch.zeros_like(w))
+    return ((mat.to(gram.dtype) @ (V * winv)) @ V.transpose(0, 1)).to(mat.dtype)
 
 
 def _project_out(U: torch.Tensor, M: torch.Tensor) -> torch.Tensor:
@@ -107,7 +120,7 @@ class TuckerRiemannian:
             loss = loss_fn(T)
             grads = torch.autograd.grad(loss, [dG] + dUs, retain_graph=retain_graph)
         g_core, g_fac = grads[0], grads[1:]
-        deltas = [_solve_right(_project_out(u, g), _core_gram(G, i)) for i, (u, g) in enumerate(zip(Us, g_fac))]
+        deltas = [_solve_right(_project_out(u, g), _core_gram(G, i, wide=True)) for i, (u, g) in enumerate(zip(Us, g_fac))]
         return TuckerTangentVector(Tucker(G, Us), g_core, deltas), loss.detach()
 
     @staticmethod
@@ -126,7 +139,7 @@ class TuckerRiemannian:
                 if j != i:
                     t = _mode_dot(t, m, j)
             w = v @ (_unfold(t, i) @ _unfold(G, i).transpose(0, 1))           # n_i x r_i
-            deltas.append(_solve_right(_project_out(u, w), _core_gram(G, i)))
+            deltas.append(_solve_right(_project_out(u, w), _core_gram(G, i, wide=True)))
         return TuckerTangentVector(x, dG, deltas)
 
 
@@ -185,7 +198,7 @@ class SFTuckerRiemannian:
 
     @staticmethod
     def _shared_gram(G: torch.Tensor, nreg: int, ns: int) -> torch.Tensor:
-        return sum(_core_gram(G, m) for m in range(nreg, nreg + ns))
+        return sum(_core_gram(G, m, wide=True) for m in range(nreg, nreg + ns))     # only ever inverted
 
     @staticmethod
     def grad(loss_fn: Callable[[SFTucker], torch.Tensor], x: SFTucker, retain_graph: bool = False):
@@ -202,7 +215,7 @@ class SFTuckerRiemannian:
             loss = loss_fn(T)
             grads = torch.autograd.grad(loss, [dG] + dRs + [dE], retain_graph=retain_graph)
         g_core, g_reg, g_e = grads[0], grads[1:1 + nreg], grads[-1]
-        d_reg = [_solve_right(_project_out(u, g), _core_gram(G, i)) for i, (u, g) in enumerate(zip(Rs, g_reg))]
+        d_reg = [_solve_right(_project_out(u, g), _core_gram(G, i, wide=True)) for i, (u, g) in enumerate(zip(Rs, g_reg))]
         d_e = _solve_right(_project_out(E, g_e), SFTuckerRiemannian._shared_gram(G, nreg, ns))
         return SFTuckerTangentVector(SFTucker(G, Rs, ns, E), g_core, d_reg, d_e), loss.detach()
 
@@ -223,7 +236,7 @@ class SFTuckerRiemannian:
                     t = _mode_dot(t, m, j)
             return zf[i] @ (_unfold(t, i) @ _unfold(G, i).transpose(0, 1))
 
-        d_reg = [_solve_right(_project_out(xf[i], mode_term(i)), _core_gram(G, i)) for i in range(nreg)]
+        d_reg = [_solve_right(_project_out(xf[i], mode_term(i)), _core_gram(G, i, wide=True)) for i in range(nreg)]
         w = sum(mode_term(m) for m in range(nreg, nreg + ns))
         d_e = _solve_right(_project_out(x.shared_factor, w), SFTuckerRiemannian._shared_gram(G, nreg, ns))
         return SFTuckerTangentVector(x, dG, d_reg, d_e)

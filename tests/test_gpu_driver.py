@@ -100,3 +100,36 @@ def test_one_full_epoch_at_the_readme_rank(tmp_path, capsys):
     print(f"\none WN18RR epoch: {rec['epoch_time']:.1f} s train, {rec['eval_time']:.2f} s test eval, "
           f"loss {rec['train_loss']:.5f}, val MRR {rec['val_mrr']:.4f}")
     assert len(state.metrics.mrr.val) == 1
+
+
+def test_core_basis_survives_an_eigensolver_failure(monkeypatch):
+    """``round()`` takes the left basis of a core unfolding from ``eigh`` of its Gram matrix; rocSOLVER's
+    divide-and-conquer does not always converge in fp32 (seen after 7 epochs of small-step RSGD on WN18RR).
+    The float64 retry and the SVD fallback must give the same subspace."""
+    from r_tucker_amd import tucker
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lead = torch.randn(40, 12, device="cuda", generator=g) @ torch.randn(12, 1600, device="cuda", generator=g)
+    mat = lead + 1e-3 * torch.randn(40, 1600, device="cuda", generator=g)        # a clear gap after 12 directions
+    want = tucker._truncated_left_basis(mat, 12)
+    proj = want @ want.T
+    real = torch.linalg.eigh
+    seen = []
+
+    def fp32_fails(a, *args, **kw):
+        seen.append(a.dtype)
+        if a.dtype == torch.float32:
+            raise torch.linalg.LinAlgError("forced: did not converge")
+        return real(a, *args, **kw)
+
+    monkeypatch.setattr(torch.linalg, "eigh", fp32_fails)
+    got = tucker._truncated_left_basis(mat, 12)
+    assert seen == [torch.float32, torch.float64] and got.dtype == torch.float32
+    assert (got @ got.T - proj).abs().max().item() < 1e-4
+
+    def always_fails(a, *args, **kw):
+        raise torch.linalg.LinAlgError("forced")
+
+    monkeypatch.setattr(torch.linalg, "eigh", always_fails)
+    got = tucker._truncated_left_basis(mat, 12)
+    assert (got @ got.T - proj).abs().max().item() < 1e-4
+    assert (got.T @ got - torch.eye(12, device="cuda")).abs().max().item() < 1e-5
