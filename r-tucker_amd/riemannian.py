@@ -38,22 +38,27 @@ def _core_gram(core: torch.Tensor, mode: int, wide: bool = False) -> torch.Tenso
     return u @ u.transpose(0, 1)
 
 
-# Eigenvalues of the core Gram matrix below RCOND * largest count as zero in ``_solve_right``: singular values
-# of the core unfolding below 1e-4 of the largest.
-RCOND = 1e-8
+# Regularisation of the core Gram matrix in ``_solve_right``, relative to its trace, by the precision of the data.
+RCOND = {torch.float32: 1e-8, torch.float64: 1e-14}
 
 
 def _solve_right(mat: torch.Tensor, gram: torch.Tensor) -> torch.Tensor:
-    """``mat @ gram^+`` for the symmetric positive semidefinite core Gram matrix, as a TRUNCATED pseudo-inverse
-    (in ``gram``'s precision; the result in ``mat``'s).  The gauge-fixed factor components of a tangent vector
-    carry the inverse of the core's Gram matrix; a core unfolding that has lost a direction numerically (seen
-    after ~1400 small steps on WN18RR: one singular value of the mode-1 unfolding collapsed) made the plain
-    solve return entries of 1e37 in one column, finite until multiplied by the learning rate.  A direction the
-    core does not use has no tangent component of its own -- the core component ``dG`` still moves it."""
-    w, V = torch.linalg.eigh(gram)
-    keep = w > RCOND * w[-1].clamp_min(0)
-    winv = torch.where(keep, 1.0 / torch.where(keep, w, torch.ones_like(w)), torch.zeros_like(w))
-    return ((mat.to(gram.dtype) @ (V * winv)) @ V.transpose(0, 1)).to(mat.dtype)
+    """``mat @ (gram + eps I)^-1`` for the symmetric positive semidefinite core Gram matrix, ``eps = RCOND *
+    trace(gram)`` (Cholesky in ``gram``'s precision, one small inverse; no eigensolver, no host sync).  The
+    gauge-fixed factor components of a tangent vector carry the inverse of the core's Gram matrix; a core
+    unfolding that has lost a direction numerically (seen after ~1400 small steps on WN18RR: one singular value
+    of the mode-1 unfolding collapsed) made the plain solve return entries of 1e37 in one column, finite until
+    multiplied by the learning rate.  With the shift the amplification is bounded by 1e8 / trace, directions the
+    core uses (eigenvalues >> eps) are untouched to 1e-8 relative, and a direction it does not use gets next to
+    no factor component of its own -- the core component ``dG`` still moves it.  A zero core (trace 0) gives 0."""
+    n = gram.shape[0]
+    tr = gram.diagonal().sum()
+    eps = RCOND.get(mat.dtype, 1e-8) * tr
+    live = (tr > 0).to(gram.dtype)
+    eye = torch.eye(n, dtype=gram.dtype, device=gram.device)
+    chol = torch.linalg.cholesky_ex(gram + (eps + (1.0 - live)) * eye).L      # (trace 0: factor I, result masked)
+    inv = torch.cholesky_inverse(chol) * live
+    return mat @ inv.to(mat.dtype)
 
 
 def _project_out(U: torch.Tensor, M: torch.Tensor) -> torch.Tensor:

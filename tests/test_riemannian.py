@@ -181,9 +181,9 @@ def test_optimizers_descend_and_keep_the_manifold(sym, opt_name):
 @pytest.mark.parametrize("dt", [torch.float64, torch.float32])
 def test_gradient_at_a_core_that_lost_a_direction_stays_bounded(sym, dt):
     """A core unfolding with a (numerically) dead direction: the gauge-fixed factor components carry the inverse
-    of the core's Gram matrix, which must be a truncated pseudo-inverse -- the plain solve returned 1e37 in one
-    column after ~1400 RSGD steps on WN18RR.  The component along the dead direction is zero, the others are
-    those of the same point with the direction removed outright, and a step from there stays finite."""
+    of the core's Gram matrix, which is regularised (shift eps = RCOND * trace) -- the plain solve returned 1e37
+    in one column after ~1400 RSGD steps on WN18RR.  A singular value s of the unfolding is then amplified by
+    s / (s^2 + eps) <= 1 / (2 sqrt(eps)) instead of 1 / s; the step from there stays finite."""
     x = point(sym)
     core = x.core.clone()
     core[:, :, -1] = 1e-12 * core[:, :, -1]          # mode-2 direction numerically dead
@@ -195,10 +195,13 @@ def test_gradient_at_a_core_that_lost_a_direction_stays_bounded(sym, dt):
     g = torch.Generator().manual_seed(3)
     W = torch.randn(xs.full().shape, dtype=dt, generator=g)
     grad, _ = geo(sym).grad(lambda T: (T.full() * W).sum(), xs)
-    d_last = deltas(grad, sym)[-1]
     assert all(torch.isfinite(d).all() for d in deltas(grad, sym)) and torch.isfinite(grad.delta_core).all()
-    assert d_last[:, -1].abs().max().item() <= 1e-6 * d_last.abs().max().item()      # no component of its own
-    assert max(d.abs().max().item() for d in deltas(grad, sym)) < 1e3 * W.abs().max().item() / core[..., :-1].abs().min().item()
+    from r_tucker_amd.riemannian import RCOND
+    eps = RCOND[dt] * float((xs.core.double() ** 2).sum())        # trace of any mode's Gram matrix = ||core||^2
+    if sym:
+        eps *= 2                                                   # (the shared factor sums the Gram matrices of two modes)
+    bound = float(W.abs().sum()) / (2 * eps ** 0.5)                # |Euclidean gradient entry| <= sum |W| (orthonormal factors)
+    assert max(d.abs().max().item() for d in deltas(grad, sym)) <= bound
     assert torch.isfinite(grad.norm())
     moved = ((-0.1) * grad + geo(sym).TangentVector(xs)).construct().round(tuple(xs.core.shape))
     assert torch.isfinite(moved.full()).all()
