@@ -21,6 +21,7 @@ from torch import nn
 from . import ops
 from .evaluation import DeviceFilter, evaluate as _evaluate
 from .tucker import SFTucker, Tucker
+from . import tucker as _tucker
 from .utils.storage import Losses, Metrics, StateDict
 from .utils.utils import Timer
 
@@ -149,6 +150,9 @@ def train(model, optimizer, train_set, val_set, test_set, config, regulizer, sch
         for split, m in (("val", val_metrics), ("test", test_metrics)):
             for k, v in m.items():
                 record[f"{split}_{k}"] = v
+        if _tucker.FALLBACKS:        # slow paths of the retraction taken this epoch (tucker.py)
+            record["fallbacks"] = dict(_tucker.FALLBACKS)
+            _tucker.FALLBACKS.clear()
         if wandb_run is not None:
             wandb_run.log(record)
         if log is not None:

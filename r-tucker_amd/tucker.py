@@ -22,6 +22,8 @@ reference does the same through tucker_riemopt's torch backend); the scoring ari
 """
 from __future__ import annotations
 
+import collections
+
 from typing import Sequence
 
 import torch
@@ -50,6 +52,10 @@ def _gram_norm(core: torch.Tensor, grams: Sequence[torch.Tensor]) -> torch.Tenso
     return torch.sqrt(torch.clamp((t * core).sum(), min=0.0))
 
 
+# How often the fast paths below gave way to a slower one (the driver logs and clears this once per epoch).
+FALLBACKS = collections.Counter()
+
+
 def _cholesky_qr2(D: torch.Tensor):
     """Thin QR of a tall-skinny ``D`` by two rounds of Cholesky QR on its Gram matrix (the Gram products are the
     split-K HIP GEMM on the GPU): O(n k^2) flops in three chip-filling GEMMs instead of k Householder
@@ -61,16 +67,29 @@ def _cholesky_qr2(D: torch.Tensor):
     if not bool((scale > 0).all()):
         return None
     Dn = D / scale
+    k = D.shape[1]
+    eye = torch.eye(k, dtype=D.dtype, device=D.device)
     R_total = None
     Q = Dn
-    for _ in range(2):
+    rounds = 2
+    i = 0
+    while i < rounds:
         S = _tn(Q, Q)
         L, info = torch.linalg.cholesky_ex(S)
         if int(info) != 0:
-            return None
+            if i > 0:
+                return None
+            # condition number above ~3e3 (its square does not survive fp32): one round on the SHIFTED Gram matrix
+            # brings it down to ~1e3, two plain rounds finish (shifted Cholesky QR 3)
+            FALLBACKS["cholesky_qr_shifted"] += 1
+            L, info = torch.linalg.cholesky_ex(S + 1e-6 * k * eye)            # diag(S) = 1: trace = k
+            if int(info) != 0:
+                return None
+            rounds = 3
         Q = torch.linalg.solve_triangular(L.transpose(0, 1), Q, upper=True, left=False)      # Q <- Q L^-T
         R_total = L.transpose(0, 1) if R_total is None else L.transpose(0, 1) @ R_total
-    err = (_tn(Q, Q) - torch.eye(Q.shape[1], dtype=Q.dtype, device=Q.device)).abs().max()
+        i += 1
+    err = (_tn(Q, Q) - eye).abs().max()
     if not bool(err < 1e-4):
         return None
     return Q, R_total * scale          # D = Q (R diag(scale))
@@ -88,7 +107,8 @@ def _qr_thin(f: torch.Tensor, n_orth: int = 0):
     D = D - U @ C
     qr = _cholesky_qr2(D)
     if qr is None:
-        return torch.linalg.qr(f)
+        FALLBACKS["householder_qr"] += 1
+        qr = torch.linalg.qr(D)                 # of the new block only: a quarter of the flops of qr(f)
     Qd, Rd = qr
     R = f.new_zeros((k, k))
     R[:n_orth, :n_orth] = torch.eye(n_orth, dtype=f.dtype, device=f.device)
@@ -116,16 +136,32 @@ def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
         r = mat.shape[0]
     if mat.is_cuda and mat.dtype == torch.float32 and mat.shape[1] >= 4 * mat.shape[0]:
         gram = mat @ mat.transpose(0, 1)
-        # rocSOLVER's divide-and-conquer gives up on Gram matrices whose small eigenvalues are rounding noise
-        # (a small step leaves the new directions 1e-4 of the old ones: 1e-8 after squaring): retry in
-        # float64, then fall back to the SVD of the unfolding itself
-        for g in (gram, gram.double()):
-            try:
-                w, V = torch.linalg.eigh(g)                        # ascending eigenvalues
-            except torch.linalg.LinAlgError:
-                continue
+        try:
+            w, V = torch.linalg.eigh(gram)                             # ascending eigenvalues
+            if torch.isfinite(V).all():
+                return V[:, -r:].flip(1)
+        except torch.linalg.LinAlgError:
+            pass
+        # rocSOLVER's divide-and-conquer gives up on Gram matrices whose small eigenvalues are rounding noise: a
+        # small step leaves the new directions 1e-4 of the old ones, 1e-8 after squaring -- which is exactly when
+        # the dominant subspace is trivially separated.  Orthogonal iteration from the leading coordinates
+        # converges by (sigma_{r+1} / sigma_r)^2 per round; accepted when the subspace is invariant to 1e-5.
+        FALLBACKS["eigh_orthogonal_iteration"] += 1
+        Q = torch.eye(gram.shape[0], r, dtype=gram.dtype, device=gram.device)
+        for _ in range(4):
+            Q = torch.linalg.qr(gram @ Q)[0]
+        GQ = gram @ Q
+        resid = torch.linalg.matrix_norm(GQ - Q @ (Q.transpose(0, 1) @ GQ)) / torch.linalg.matrix_norm(gram)
+        if bool(resid < 1e-5):
+            return Q
+        FALLBACKS["eigh_float64"] += 1
+        try:
+            w, V = torch.linalg.eigh(gram.double())
             if torch.isfinite(V).all():
                 return V[:, -r:].flip(1).to(mat.dtype)
+        except torch.linalg.LinAlgError:
+            pass
+        FALLBACKS["svd"] += 1
     U, _, _ = torch.linalg.svd(mat, full_matrices=False)
     return U[:, :r]
 

@@ -105,13 +105,13 @@ def test_one_full_epoch_at_the_readme_rank(tmp_path, capsys):
 def test_core_basis_survives_an_eigensolver_failure(monkeypatch):
     """``round()`` takes the left basis of a core unfolding from ``eigh`` of its Gram matrix; rocSOLVER's
     divide-and-conquer does not always converge in fp32 (seen after 7 epochs of small-step RSGD on WN18RR).
-    The float64 retry and the SVD fallback must give the same subspace."""
+    Orthogonal iteration (clear gap), the float64 retry (no gap) and the SVD fallback give the same subspace."""
     from r_tucker_amd import tucker
     g = torch.Generator(device="cuda").manual_seed(5)
     lead = torch.randn(40, 12, device="cuda", generator=g) @ torch.randn(12, 1600, device="cuda", generator=g)
-    mat = lead + 1e-3 * torch.randn(40, 1600, device="cuda", generator=g)        # a clear gap after 12 directions
-    want = tucker._truncated_left_basis(mat, 12)
-    proj = want @ want.T
+    gap = lead + 1e-3 * torch.randn(40, 1600, device="cuda", generator=g)        # a clear gap after 12 directions
+    flat = torch.randn(40, 1600, device="cuda", generator=g)                      # no gap anywhere
+    want = {id(m): tucker._truncated_left_basis(m, 12) for m in (gap, flat)}
     real = torch.linalg.eigh
     seen = []
 
@@ -121,15 +121,21 @@ def test_core_basis_survives_an_eigensolver_failure(monkeypatch):
             raise torch.linalg.LinAlgError("forced: did not converge")
         return real(a, *args, **kw)
 
+    def same_subspace(got, ref, tol):
+        assert got.dtype == torch.float32 and (got.T @ got - torch.eye(12, device="cuda")).abs().max().item() < 1e-5
+        assert (got @ got.T - ref @ ref.T).abs().max().item() < tol
+
     monkeypatch.setattr(torch.linalg, "eigh", fp32_fails)
-    got = tucker._truncated_left_basis(mat, 12)
-    assert seen == [torch.float32, torch.float64] and got.dtype == torch.float32
-    assert (got @ got.T - proj).abs().max().item() < 1e-4
+    tucker.FALLBACKS.clear()
+    same_subspace(tucker._truncated_left_basis(gap, 12), want[id(gap)], 1e-4)
+    assert seen == [torch.float32] and dict(tucker.FALLBACKS) == {"eigh_orthogonal_iteration": 1}
+    same_subspace(tucker._truncated_left_basis(flat, 12), want[id(flat)], 1e-3)
+    assert seen == [torch.float32, torch.float32, torch.float64] and tucker.FALLBACKS["eigh_float64"] == 1
 
     def always_fails(a, *args, **kw):
         raise torch.linalg.LinAlgError("forced")
 
     monkeypatch.setattr(torch.linalg, "eigh", always_fails)
-    got = tucker._truncated_left_basis(mat, 12)
-    assert (got @ got.T - proj).abs().max().item() < 1e-4
-    assert (got.T @ got - torch.eye(12, device="cuda")).abs().max().item() < 1e-5
+    same_subspace(tucker._truncated_left_basis(flat, 12), want[id(flat)], 1e-3)
+    assert tucker.FALLBACKS["svd"] == 1
+    tucker.FALLBACKS.clear()
