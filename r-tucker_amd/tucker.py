@@ -129,36 +129,31 @@ def _polish(factor: torch.Tensor):
 def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
     """The r leading left singular vectors of ``mat`` (columns).  Core unfoldings are short and wide (2r x 4r^2):
     on the GPU in fp32 they come from the eigenvectors of the small Gram matrix ``mat mat^T`` (one GEMM + one
-    2r x 2r symmetric eigenproblem instead of a Jacobi SVD of the wide matrix); the subspace wanted is the
-    dominant one, separated from the rest by the size of the step, so squaring the spectrum costs nothing
-    that matters.  Elsewhere (CPU, float64: the identity tests) the SVD itself."""
+    2r x 2r symmetric eigenproblem instead of a Jacobi SVD of the wide matrix).
+
+    Squaring the spectrum puts the fp32 noise floor at 3e-4 of the largest singular value.  That is harmless
+    while the r-th direction is well above it -- and wrong once the core has dead directions that the step's
+    new ones (singular values ~ the step length, 1e-3 of ||T|| and less) should replace: measured on WN18RR, half
+    of a step's change was lost in ``round()`` from epoch 16 on.  When the smallest kept eigenvalue is within
+    1e-5 of the largest, the Gram matrix is therefore accumulated in float64 (exact products of fp32 values) and
+    its eigenvectors are taken on the host (LAPACK: 15 ms for 400 x 400; rocSOLVER's float64 ``syevd`` needs
+    80 ms and its fp32 divide-and-conquer does not always converge on such spectra).  Elsewhere (CPU, float64:
+    the identity tests) the SVD itself."""
     if mat.shape[0] <= r:
         r = mat.shape[0]
     if mat.is_cuda and mat.dtype == torch.float32 and mat.shape[1] >= 4 * mat.shape[0]:
-        gram = mat @ mat.transpose(0, 1)
         try:
-            w, V = torch.linalg.eigh(gram)                             # ascending eigenvalues
-            if torch.isfinite(V).all():
+            w, V = torch.linalg.eigh(mat @ mat.transpose(0, 1))        # ascending eigenvalues
+            if bool(torch.isfinite(V).all()) and bool(w[-r] > 1e-5 * w[-1]):
                 return V[:, -r:].flip(1)
         except torch.linalg.LinAlgError:
             pass
-        # rocSOLVER's divide-and-conquer gives up on Gram matrices whose small eigenvalues are rounding noise: a
-        # small step leaves the new directions 1e-4 of the old ones, 1e-8 after squaring -- which is exactly when
-        # the dominant subspace is trivially separated.  Orthogonal iteration from the leading coordinates
-        # converges by (sigma_{r+1} / sigma_r)^2 per round; accepted when the subspace is invariant to 1e-5.
-        FALLBACKS["eigh_orthogonal_iteration"] += 1
-        Q = torch.eye(gram.shape[0], r, dtype=gram.dtype, device=gram.device)
-        for _ in range(4):
-            Q = torch.linalg.qr(gram @ Q)[0]
-        GQ = gram @ Q
-        resid = torch.linalg.matrix_norm(GQ - Q @ (Q.transpose(0, 1) @ GQ)) / torch.linalg.matrix_norm(gram)
-        if bool(resid < 1e-5):
-            return Q
-        FALLBACKS["eigh_float64"] += 1
+        FALLBACKS["eigh_float64_host"] += 1
+        m64 = mat.double()
         try:
-            w, V = torch.linalg.eigh(gram.double())
-            if torch.isfinite(V).all():
-                return V[:, -r:].flip(1).to(mat.dtype)
+            w, V = torch.linalg.eigh((m64 @ m64.transpose(0, 1)).cpu())
+            if bool(torch.isfinite(V).all()):
+                return V[:, -r:].flip(1).to(device=mat.device, dtype=mat.dtype)
         except torch.linalg.LinAlgError:
             pass
         FALLBACKS["svd"] += 1

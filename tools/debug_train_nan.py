@@ -38,6 +38,33 @@ def finite(name, *ts):
     return True
 
 
+from r_tucker_amd import tucker as _tk  # noqa: E402
+
+
+def core_spectrum(core):
+    out = []
+    for m in range(3):
+        u = core.movedim(m, 0).reshape(core.shape[m], -1).double()
+        sv = torch.linalg.svdvals(u)
+        out.append((sv[0].item(), sv[-1].item()))
+    return out
+
+
+gs = torch.Generator(device=dev).manual_seed(11)
+sh = torch.randint(0, len(data.entities), (4096,), device=dev, generator=gs)
+so = torch.randint(0, len(data.entities), (4096,), device=dev, generator=gs)
+sr = torch.randint(0, len(data.relations), (4096,), device=dev, generator=gs)
+
+
+def entries(core, R, S, O):
+    """T[r, h, o] at the sampled triples (float64)."""
+    t = torch.einsum("abc,na->nbc", core.double(), R[sr].double())
+    t = torch.einsum("nbc,nb->nc", t, S[sh].double())
+    return (t * O[so].double()).sum(dim=1)
+
+
+hist = []
+prev_loss = None
 step = 0
 for epoch in range(1, max_epochs + 1):
     model.train()
@@ -56,11 +83,35 @@ for epoch in range(1, max_epochs + 1):
         if not ok:
             print(f"first failure in fit: epoch {epoch} batch {b} step {step}; attributes of direction: {[k for k in vars(d)]}")
             sys.exit(0)
+        lr_now = opt.param_groups[0]["lr"]
+        built = ((-lr_now) * d + type(d)(d.point)).construct()
+        want = entries(built.core, *built.factors)
+        old = entries(d.point.core, *d.point.factors)
         opt.step()
+        got = entries(model.core.data, model.R.weight.data, model.S.weight.data, model.O.weight.data)
+        rel = ((got - want).norm() / want.norm()).item()
+        upd = ((want - old).norm() / want.norm()).item()
+        if rel > 0.5 * max(upd, 1e-6) and rel > 1e-4:
+            print(f"RETRACTION MISMATCH at epoch {epoch} batch {b} step {step}: |round(x - lr d) - (x - lr d)| / |.| = {rel:.3e}, "
+                  f"update size {upd:.3e}, fallbacks {dict(_tk.FALLBACKS)}")
+            print("   core spectrum after:", core_spectrum(model.core.data))
+            sys.exit(0)
         if not finite("params after step", model.core.data, model.R.weight.data, model.S.weight.data, model.O.weight.data):
             print(f"first failure in step: epoch {epoch} batch {b} step {step}; loss {opt.loss.item()} grad norm {gn.item()}")
             sys.exit(0)
-        tot += opt.loss.item()
+        cur = opt.loss.item()
+        hist.append((step, cur, gn.item(), dict(_tk.FALLBACKS), max(x.abs().max().item() for x in d.delta_factors),
+                     d.delta_core.abs().max().item()))
+        _tk.FALLBACKS.clear()
+        if prev_loss is not None and cur > prev_loss + 0.05:
+            print(f"LOSS JUMP at epoch {epoch} batch {b} step {step}: {prev_loss:.4f} -> {cur:.4f}")
+            for h in hist[-6:]:
+                print("   step %d loss %.5f gnorm %.3e fallbacks %s max|dU| %.3e max|dG| %.3e" % h)
+            print("   core spectrum (max, min singular value per mode):", core_spectrum(model.core.data))
+            print("   factor orthonormality:", [(w.data.T @ w.data - torch.eye(w.shape[1], device=dev)).abs().max().item() for w in (model.R.weight, model.S.weight, model.O.weight)])
+            sys.exit(0)
+        prev_loss = 0.9 * prev_loss + 0.1 * cur if prev_loss is not None else cur
+        tot += cur
         step += 1
     opt.param_groups[0]["lr"] *= decay
     print(f"epoch {epoch}: mean loss {tot / (n // B):.6f}, core norm {model.core.data.norm().item():.4e}, lr {opt.param_groups[0]['lr']:.2f}", flush=True)
