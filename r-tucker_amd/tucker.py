@@ -126,6 +126,19 @@ def _polish(factor: torch.Tensor):
     return _cholesky_qr2(factor)
 
 
+def _host_eigh(gram: torch.Tensor):
+    """``eigh`` of a small symmetric matrix on the host with at most 8 threads: torch sizes its intra-op pool to
+    the machine (256 hardware threads on the MI355X hosts), which slows a 400 x 400 problem from 8 ms to > 100 ms."""
+    n = torch.get_num_threads()
+    if n <= 8:
+        return torch.linalg.eigh(gram)
+    try:
+        torch.set_num_threads(8)
+        return torch.linalg.eigh(gram)
+    finally:
+        torch.set_num_threads(n)
+
+
 def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
     """The r leading left singular vectors of ``mat`` (columns).  Core unfoldings are short and wide (2r x 4r^2):
     on the GPU in fp32 they come from the eigenvectors of the small Gram matrix ``mat mat^T`` (one GEMM + one
@@ -151,7 +164,7 @@ def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
         FALLBACKS["eigh_float64_host"] += 1
         m64 = mat.double()
         try:
-            w, V = torch.linalg.eigh((m64 @ m64.transpose(0, 1)).cpu())
+            w, V = _host_eigh((m64 @ m64.transpose(0, 1)).cpu())
             if bool(torch.isfinite(V).all()):
                 return V[:, -r:].flip(1).to(device=mat.device, dtype=mat.dtype)
         except torch.linalg.LinAlgError:
