@@ -299,6 +299,21 @@ int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t 
 int rtk_rank_metrics_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double *acc5, void *stream);
 
 /*
+ * Batched small Cholesky-QR factor step, float64: for each of `batch` symmetric positive semidefinite k x k Gram
+ * matrices S = W^T W (row-major, contiguous, k <= 256), with D = sqrt(diag S) if `equilibrate` (else I) and
+ *     A = D^-1 S D^-1 + (shift_diag + shift_trace * trace(S)) I = L L^T,
+ * the upper triangular  R = L^T D  and  X = D^-1 L^-T :  W X has orthonormal columns, W = (W X) R, and
+ * X X^T = (S + shift)^-1 when not equilibrated.  One workgroup per matrix, one launch, no workspace, no host
+ * synchronisation, no failure status (a pivot that cancelled below 1e-14 of its diagonal entry is floored there;
+ * trace(S) <= 0 gives zero outputs).  The Riemannian optimizer step orthonormalises and inverts the core's Gram
+ * matrices with it (replaces tucker_riemopt's QR / SVD / solve calls reached from
+ * src/model/asymmetric/optim.py:86-89,107-108 and src/model/symmetric/optim.py:80-83,101-103).
+ * The three buffers must be distinct.
+ */
+int rtk_gram_factor_f64(const void *S, int64_t batch, int k, int equilibrate, double shift_diag, double shift_trace,
+                        void *R_out, void *X_out, void *stream);
+
+/*
  * The same ranking with the entity dimension sharded over GPUs (no gather of the scores): a rank
  * holds columns [col0, col0 + n_local) of the score matrix; the count is a sum over columns.
  *   1. rtk_target_scores_f32: pt_out[d] = P[d, obj_idx[d] - col0] where this rank owns the queried

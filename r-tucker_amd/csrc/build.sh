@@ -5,13 +5,17 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-function"
-SRCS="rtk_abi rtk_gemm_f32 rtk_gemm_sf16 rtk_query rtk_query_bwd rtk_score_split rtk_score_ws rtk_score_bf16 rtk_rank rtk_bce"
+SRCS="rtk_abi rtk_gemm_f32 rtk_gemm_sf16 rtk_query rtk_query_bwd rtk_score_split rtk_score_ws rtk_score_bf16 rtk_rank rtk_bce rtk_chol"
 pids=()
 objs=()
+# incremental: a source is recompiled when it, any header here or the public header is newer than its object
+# (RTK_REBUILD=1 forces everything)
+newest_hdr=$(ls -t *.h ../../include/*.h build.sh | head -1)
 for f in $SRCS; do
+  objs+=(obj/$f.o)
+  if [ -z "$RTK_REBUILD" ] && [ obj/$f.o -nt $f.hip ] && [ obj/$f.o -nt "$newest_hdr" ]; then continue; fi
   ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
   pids+=($!)
-  objs+=(obj/$f.o)
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librtucker_hip.so" "${objs[@]}"

@@ -55,25 +55,53 @@ def extract_tensor(model):
     return Tucker(model.core.data, [model.R.weight, model.S.weight, model.O.weight])
 
 
+class RegularisedLoss:
+    """``loss_fn`` of ``train.py:79``: ``T -> data_term(T) + coeff * T.norm() ** 2``, callable on any container like
+    the reference's lambda.  It also says what it is made of (``riemannian_split``), which lets
+    ``TuckerRiemannian.grad`` / ``SFTuckerRiemannian.grad`` take the squared-norm term analytically at a manifold
+    point instead of differentiating it through the factor Gram matrices (``riemannian._split_loss``)."""
+
+    def __init__(self, data_term, coeff):
+        self.data_term, self.coeff = data_term, coeff
+        self.riemannian_split = (data_term, coeff)
+
+    def __call__(self, T):
+        return self.data_term(T) + self.coeff * T.norm() ** 2
+
+
 def batch_loss_fn(model, subject_idx, relation_idx, flt, item_ids, label_smoothing, regularization_coeff):
-    """``loss_fn`` of ``train.py:79`` for one batch, as a function of the container ``T``."""
+    """``loss_fn`` of ``train.py:79`` for one batch, as a function of the container ``T``.
+    ``regularization_coeff``: a float or a 0-dim device tensor (the captured step keeps it in device memory)."""
     sym = _is_symmetric(model)
 
-    def loss_fn(T):
+    def bce(T):
         if sym:
             core, R, S, O = T.core, T.regular_factors[0], T.shared_factor, T.shared_factor
         else:
             core, (R, S, O) = T.core, T.factors
-        bce = ops.bce_loss_1vN(core, R, S, O, subject_idx, relation_idx, flt, item_ids, label_smoothing=label_smoothing)
-        return bce + regularization_coeff * T.norm() ** 2
+        return ops.bce_loss_1vN(core, R, S, O, subject_idx, relation_idx, flt, item_ids, label_smoothing=label_smoothing)
 
-    return loss_fn
+    return RegularisedLoss(bce, regularization_coeff)
+
+
+def _captured_step(model, optimizer, train_flt, batch_size, label_smoothing):
+    """The per-batch step as a replayable HIP graph (``graphstep.CapturedTrainStep``), kept on the optimizer so
+    that later epochs reuse the capture."""
+    from .graphstep import CapturedTrainStep
+    key = (id(model), id(train_flt), int(batch_size), float(label_smoothing))
+    cur = getattr(optimizer, "_rtk_captured", None)
+    if cur is None or cur[0] != key:
+        cur = (key, CapturedTrainStep(model, optimizer, train_flt, batch_size, label_smoothing, extract_tensor, batch_loss_fn))
+        optimizer._rtk_captured = cur
+    return cur[1]
 
 
 def train_one_epoch(model, optimizer, train_flt: DeviceFilter, batch_size, label_smoothing, regularization_coeff=1e-4,
                     max_batches=None, log=None):
     """``train.py:69-91``: one pass over the (s, r) pairs of the train split; returns the mean loss and mean
-    Riemannian gradient norm over the batches."""
+    Riemannian gradient norm over the batches.  The batch step (``fit`` + ``step``) runs from a HIP graph after
+    its first two eager executions; loss and gradient norm are summed on the device (one synchronisation per
+    epoch instead of the reference's two ``.item()`` per batch in its progress bar)."""
     model.train()
     dev = train_flt.device
     n = train_flt.features.shape[0]
@@ -81,25 +109,19 @@ def train_one_epoch(model, optimizer, train_flt: DeviceFilter, batch_size, label
     if max_batches is not None:
         n_batches = min(n_batches, max_batches)
     perm = torch.randperm(n, device=dev)
-    train_loss = torch.zeros((), device=dev)
-    train_grad_norm = torch.zeros((), device=dev)
+    step = _captured_step(model, optimizer, train_flt, batch_size, label_smoothing)
     with ops.index_check("deferred"):                   # ids come from the dataset's own vocabulary: one check per epoch
+        step.begin_epoch(regularization_coeff)
         for b in range(n_batches):
-            ids = perm[b * batch_size:(b + 1) * batch_size]
-            f = train_flt.features[ids]
-            loss_fn = batch_loss_fn(model, f[:, 0].contiguous(), f[:, 1].contiguous(), train_flt, ids, label_smoothing,
-                                    regularization_coeff)
-            x_k = extract_tensor(model)
-            grad_norm = optimizer.fit(loss_fn, x_k)
-            optimizer.step()
-            train_grad_norm += grad_norm.detach()
-            train_loss += optimizer.loss.detach()
+            step.run(perm[b * batch_size:(b + 1) * batch_size])
             optimizer.zero_grad(set_to_none=True)
             if log is not None and (b + 1) % 50 == 0:
-                log(f"  batch {b + 1}/{n_batches}: loss {train_loss.item() / (b + 1):.6f}  grad norm {train_grad_norm.item() / (b + 1):.4e}")
+                ls, gs = step.totals()
+                log(f"  batch {b + 1}/{n_batches}: loss {ls / (b + 1):.6f}  grad norm {gs / (b + 1):.4e}")
+        train_loss, train_grad_norm = step.totals()
     ops.check_device_errors(dev)
     denom = max(n_batches, 1)
-    return train_loss.item() / denom, train_grad_norm.item() / denom
+    return train_loss / denom, train_grad_norm / denom
 
 
 def evaluate(model, dataset, batch_size=512, flt: DeviceFilter = None):
@@ -150,9 +172,9 @@ def train(model, optimizer, train_set, val_set, test_set, config, regulizer, sch
         for split, m in (("val", val_metrics), ("test", test_metrics)):
             for k, v in m.items():
                 record[f"{split}_{k}"] = v
-        if _tucker.FALLBACKS:        # slow paths of the retraction taken this epoch (tucker.py)
-            record["fallbacks"] = dict(_tucker.FALLBACKS)
-            _tucker.FALLBACKS.clear()
+        health = _tucker.read_health(dev)     # largest pre-polish orthonormality error of a new factor this epoch
+        if health:
+            record["retraction_health"] = max(health.values())
         if wandb_run is not None:
             wandb_run.log(record)
         if log is not None:

@@ -424,8 +424,7 @@ def gram_tn(A, B):
     """``A.T @ B``; tall-skinny fp32 GPU operands go through the split-K HIP GEMM, anything else through torch
     (the Riemannian layer is generic torch code: float64 CPU tensors in its tests)."""
     if (A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2
-            and A.shape[0] == B.shape[0] and A.shape[0] >= 8192 and A.shape[0] >= 8 * max(A.shape[1], B.shape[1])
-            and not torch.cuda.is_current_stream_capturing()):
+            and A.shape[0] == B.shape[0] and A.shape[0] >= 8192 and A.shape[0] >= 8 * max(A.shape[1], B.shape[1])):
         return _GramTN.apply(A, B)
     return A.transpose(0, 1) @ B
 

@@ -61,9 +61,18 @@ def _check_finite(what, vec_or_tensor):
 
 
 class _ManifoldOptimizer(Optimizer):
-    """Shared machinery.  ``symmetric`` selects the manifold and the parameter order."""
+    """Shared machinery.  ``symmetric`` selects the manifold and the parameter order.
+
+    State that survives a step (the previous direction of RSGD, Adam's first moment) is an EXPLICIT rank-2r tensor
+    held in persistent buffers: it is built from the tangent vector BEFORE the parameters are overwritten in place
+    (the point of a tangent vector aliases the parameter storage: ``extract_tensor`` wraps ``.data``,
+    ``train.py:37-42``; the reference constructs before its ``W.data.add_`` too, ``asymmetric/optim.py:109-114``)
+    and later steps ``copy_`` into the same storage, so a step captured into a HIP graph (``graphstep.py``) reads
+    and writes fixed addresses.  The learning rate is read from ``param_groups[0]["lr"]`` (a torch scheduler
+    drives it, ``train.py:213-215``) into a device scalar outside of any capture."""
 
     symmetric = False
+    capturable = True          # a step has no host-side state that changes from step to step
 
     def __init__(self, params, rank, max_lr, **extra):
         self.rank = tuple(rank)
@@ -73,6 +82,7 @@ class _ManifoldOptimizer(Optimizer):
         super().__init__(params, defaults)
         self.direction = None
         self.loss = None
+        self._lr_dev = None
 
     @property
     def geometry(self):
@@ -84,9 +94,52 @@ class _ManifoldOptimizer(Optimizer):
         # a vanishing gradient (e.g. exactly at an optimum) must not produce NaNs
         return (normalize_grad / torch.clamp(rgrad_norm, min=torch.finfo(rgrad_norm.dtype).tiny)) * rgrad
 
+    def refresh_lr(self):
+        """``param_groups[0]["lr"]`` -> the device scalar the step multiplies with (GPU parameters only).  Called
+        by ``step()`` unless the stream is being captured; a captured step's owner calls it before each replay."""
+        p = self.param_groups[0]["params"][0]
+        if not p.is_cuda:
+            return
+        if self._lr_dev is None:
+            self._lr_dev = torch.zeros((), dtype=p.dtype, device=p.device)
+        self._lr_dev.fill_(float(self.param_groups[0]["lr"]))
+
+    def _lr(self):
+        p = self.param_groups[0]["params"][0]
+        if not p.is_cuda:
+            return self.param_groups[0]["lr"]
+        if not torch.cuda.is_current_stream_capturing():
+            self.refresh_lr()
+        elif self._lr_dev is None:
+            raise RuntimeError("run one eager step before capturing an optimizer step")
+        return self._lr_dev
+
+    @staticmethod
+    def _tensors_of(t):
+        if isinstance(t, SFTucker):
+            return [t.core] + list(t.regular_factors) + [t.shared_factor]
+        return [t.core] + list(t.factors)
+
+    def _keep(self, slot: str, built):
+        """Store the explicit tensor ``built`` in the persistent buffers of ``slot`` (allocated on first use)."""
+        cur = getattr(self, slot, None)
+        if cur is None:
+            if built.core.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run one eager step before capturing an optimizer step")
+            if isinstance(built, SFTucker):
+                cur = SFTucker(built.core.clone(), [f.clone() for f in built.regular_factors], built.num_shared_factors,
+                               built.shared_factor.clone())
+            else:
+                cur = Tucker(built.core.clone(), [f.clone() for f in built.factors])
+            setattr(self, slot, cur)
+        else:
+            for dst, src in zip(self._tensors_of(cur), self._tensors_of(built)):
+                dst.copy_(src)
+        return cur
+
     @torch.no_grad()
     def _retract_and_write(self):
-        lr = self.param_groups[0]["lr"]
+        lr = self._lr()
         x_k = self.direction.point
         _check_finite("direction before the step", self.direction)
         _check_finite("point before the step", x_k)
@@ -134,11 +187,12 @@ class RSGDwithMomentum(_ManifoldOptimizer):
         super().__init__(params, rank, max_lr, momentum_beta=momentum_beta)
         self.momentum_beta = momentum_beta
         self.momentum = None
+        self._prev = None              # the previous direction as an explicit tensor (persistent buffers)
 
     def fit(self, loss_fn, x_k, normalize_grad: Union[float, bool] = 1.):
         geo = self.geometry
-        if self.direction is not None:
-            self.momentum = geo.project(x_k, self.direction)
+        if self._prev is not None:
+            self.momentum = geo.project(x_k, self._prev)
         else:
             self.momentum = geo.TangentVector(x_k, torch.zeros_like(x_k.core))
         _check_finite("momentum projected to the new point", self.momentum)
@@ -152,13 +206,16 @@ class RSGDwithMomentum(_ManifoldOptimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        built = self.direction.construct()      # BEFORE the write: its factors [U, dU] use the point it belongs to
         self._retract_and_write()
-        self.direction = self.direction.construct()        # explicit tensor: projected at the next point
+        self.direction = self._keep("_prev", built)   # explicit tensor: projected at the next point
 
 
 class RiemannianAdam(_ManifoldOptimizer):
     """Adam with a scalar second moment (the squared gradient norm), first moment transported by projection:
     the algorithm of ``SFTuckerAdam`` (``symmetric/optim.py:110-167``) on either manifold."""
+
+    capturable = False         # the bias correction uses a host-side step counter
 
     def __init__(self, params, rank, max_lr, betas=(0.9, 0.999), eps=1e-8, step_velocity=1):
         super().__init__(params, rank, max_lr, betas=betas, eps=eps, step_velocity=step_velocity)
@@ -166,6 +223,7 @@ class RiemannianAdam(_ManifoldOptimizer):
         self.eps = eps
         self.step_velocity = step_velocity
         self.momentum = None
+        self._m1 = None                # the first moment as an explicit tensor (persistent buffers)
         self.second_momentum = None
         self.step_t = 1
 
@@ -174,9 +232,8 @@ class RiemannianAdam(_ManifoldOptimizer):
         rgrad, self.loss = geo.grad(loss_fn, x_k)
         rgrad_norm = rgrad.norm().detach()
         b1, b2 = self.betas
-        if self.momentum is not None:
-            self.momentum = geo.project(x_k, self.momentum.construct())
-            self.momentum = b1 * self.momentum + (1 - b1) * rgrad
+        if self._m1 is not None:
+            self.momentum = b1 * geo.project(x_k, self._m1) + (1 - b1) * rgrad
         else:
             self.momentum = (1 - b1) * rgrad
         if self.second_momentum is None:
@@ -190,7 +247,7 @@ class RiemannianAdam(_ManifoldOptimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        x_new = self._retract_and_write()
-        # the first moment is a tangent vector at the OLD point: keep it attached there; fit() re-projects
-        del x_new
+        built = self.momentum.construct()       # the first moment belongs to the point about to be overwritten
+        self._retract_and_write()
+        self._keep("_m1", built)
         self.step_t += 1

@@ -22,11 +22,11 @@ reference does the same through tucker_riemopt's torch backend); the scoring ari
 """
 from __future__ import annotations
 
-import collections
-
 from typing import Sequence
 
 import torch
+
+from .smalllinalg import dominant_left_subspace, gram_factor
 
 
 def _tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
@@ -52,124 +52,104 @@ def _gram_norm(core: torch.Tensor, grams: Sequence[torch.Tensor]) -> torch.Tenso
     return torch.sqrt(torch.clamp((t * core).sum(), min=0.0))
 
 
-# How often the fast paths below gave way to a slower one (the driver logs and clears this once per epoch).
-FALLBACKS = collections.Counter()
+# Device-side health of the retraction, read (one sync) and cleared by the driver once per epoch: the largest
+# deviation from orthonormality of a new factor BEFORE its final polish, and whether anything was non-finite.
+# Nothing in a step branches on them: a step has no host synchronisation (graphstep.py captures it).
+HEALTH = {}
 
 
-def _cholesky_qr2(D: torch.Tensor):
-    """Thin QR of a tall-skinny ``D`` by two rounds of Cholesky QR on its Gram matrix (the Gram products are the
-    split-K HIP GEMM on the GPU): O(n k^2) flops in three chip-filling GEMMs instead of k Householder
-    reflections applied one after the other (rocSOLVER's geqrf spends 90 ms on a 40 943 x 400 factor, 55 % of a
-    training step once the Gram products are fixed).  Columns are normalised first (Cholesky QR squares the
-    condition number).  Returns ``None`` when the Gram matrix is numerically singular or the result is not
-    orthonormal to 1e-4 -- the caller then falls back to Householder QR."""
-    scale = torch.linalg.vector_norm(D, dim=0)
-    if not bool((scale > 0).all()):
-        return None
-    Dn = D / scale
-    k = D.shape[1]
-    eye = torch.eye(k, dtype=D.dtype, device=D.device)
-    R_total = None
-    Q = Dn
-    rounds = 2
-    i = 0
-    while i < rounds:
-        S = _tn(Q, Q)
-        L, info = torch.linalg.cholesky_ex(S)
-        if int(info) != 0:
-            if i > 0:
-                return None
-            # condition number above ~3e3 (its square does not survive fp32): one round on the SHIFTED Gram matrix
-            # brings it down to ~1e3, two plain rounds finish (shifted Cholesky QR 3)
-            FALLBACKS["cholesky_qr_shifted"] += 1
-            L, info = torch.linalg.cholesky_ex(S + 1e-6 * k * eye)            # diag(S) = 1: trace = k
-            if int(info) != 0:
-                return None
-            rounds = 3
-        Q = torch.linalg.solve_triangular(L.transpose(0, 1), Q, upper=True, left=False)      # Q <- Q L^-T
-        R_total = L.transpose(0, 1) if R_total is None else L.transpose(0, 1) @ R_total
-        i += 1
-    err = (_tn(Q, Q) - eye).abs().max()
-    if not bool(err < 1e-4):
-        return None
-    return Q, R_total * scale          # D = Q (R diag(scale))
+def _note_health(err: torch.Tensor) -> None:
+    """Fold ``err`` into the device's persistent health word IN PLACE (a replayed HIP graph keeps accumulating)."""
+    key = err.device
+    e = torch.nan_to_num(err.detach().double(), nan=float("inf")).reshape(())
+    cur = HEALTH.get(key)
+    if cur is None:
+        if err.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("tucker.HEALTH must exist before graph capture (run one eager step first)")
+        HEALTH[key] = cur = torch.zeros((), dtype=torch.float64, device=key)
+    cur.copy_(torch.maximum(cur, e))
 
 
-def _qr_thin(f: torch.Tensor, n_orth: int = 0):
-    """Thin QR of a factor.  ``n_orth`` > 0: the first ``n_orth`` columns are known to be orthonormal and (up to
-    rounding) orthogonal to the rest -- the ``[U, dU]`` factors of ``TangentVector.construct()`` -- so only the
-    remaining block needs work: ``[U, D] = [U, Q_D] [[I, U^T D], [0, R_D]]``."""
-    n, k = f.shape
-    if n_orth <= 0 or n_orth >= k or not f.is_cuda or f.dtype != torch.float32 or n < 8192:
-        return torch.linalg.qr(f)
-    U, D = f[:, :n_orth], f[:, n_orth:]
-    C = _tn(U, D)                               # ~0 by the gauge condition; removed explicitly
-    D = D - U @ C
-    qr = _cholesky_qr2(D)
-    if qr is None:
-        FALLBACKS["householder_qr"] += 1
-        qr = torch.linalg.qr(D)                 # of the new block only: a quarter of the flops of qr(f)
-    Qd, Rd = qr
-    R = f.new_zeros((k, k))
-    R[:n_orth, :n_orth] = torch.eye(n_orth, dtype=f.dtype, device=f.device)
-    R[:n_orth, n_orth:] = C
-    R[n_orth:, n_orth:] = Rd
-    return torch.cat([U, Qd], dim=1), R
+def read_health(device=None, clear: bool = True):
+    """Largest pre-polish orthonormality error since the last call (``inf``: something was not finite); one sync."""
+    out = {}
+    for k, v in HEALTH.items():
+        if device is None or k == torch.device(device):
+            out[str(k)] = float(v)
+            if clear:
+                v.zero_()
+    return out
 
 
-def _polish(factor: torch.Tensor):
-    """``(Q, R)`` with ``factor = Q R`` and Q orthonormal to fp32 rounding, for a factor that is orthonormal only up
-    to accumulated drift: the structured QR above takes the leading block ``U`` of ``[U, dU]`` as given, so
-    without this the error of the factors would add up step after step.  ``None``: leave the factor alone."""
-    if not factor.is_cuda or factor.dtype != torch.float32 or factor.shape[0] < 8192:
-        return None
-    return _cholesky_qr2(factor)
+def _orth_tall(D: torch.Tensor):
+    """``(Q, R)`` with ``D = Q R``, Q orthonormal columns, R (k x k, float64) upper triangular, for a tall-skinny
+    ``D`` by two rounds of Cholesky QR: the Gram products are the split-K HIP GEMM on the GPU, the k x k factor
+    and its inverse come from ``smalllinalg.gram_factor`` (float64, equilibrated, shifted: no failure path, no
+    host synchronisation).  rocSOLVER's Householder ``geqrf`` spends 90 ms on a 40 943 x 400 factor; this is
+    four chip-filling GEMMs.  A column of zeros stays zero (its row of R is zero)."""
+    sh = 3e-6 if D.dtype == torch.float32 else None          # fp32 Gram: shift at its rounding noise
+    X1, R1 = gram_factor(_tn(D, D), shift=sh)
+    Q = D @ X1.to(D.dtype)
+    X2, R2 = gram_factor(_tn(Q, Q), shift=None if sh is None else 1e-6)
+    return Q @ X2.to(D.dtype), R2 @ R1
 
 
-def _host_eigh(gram: torch.Tensor):
-    """``eigh`` of a small symmetric matrix on the host with at most 8 threads: torch sizes its intra-op pool to
-    the machine (256 hardware threads on the MI355X hosts), which slows a 400 x 400 problem from 8 ms to > 100 ms."""
-    n = torch.get_num_threads()
-    if n <= 8:
-        return torch.linalg.eigh(gram)
-    try:
-        torch.set_num_threads(8)
-        return torch.linalg.eigh(gram)
-    finally:
-        torch.set_num_threads(n)
+def _round_tangent_step(core: torch.Tensor, pairs, mode_factor, ranks):
+    """Truncated HOSVD of ``core x_m [U_f(m), D_f(m)]`` where every ``U`` has orthonormal columns and
+    ``U^T D = 0`` up to rounding -- the shape ``TangentVector.construct()`` produces (``pairs[f] = (U, D)``,
+    ``mode_factor[m]`` = which pair serves core axis m: (0,1,2) for Tucker, (0,1,1) for the shared-factor tensor;
+    ``ranks[f]`` the target rank of that factor).  Returns ``(new core, [new factor per pair])``.
+
+    1. ``D = Q R_d`` (thin QR of the NEW block only, Cholesky QR), so ``[U, D] = [U, Q] [[I, 0], [0, R_d]]`` (the gauge
+       condition makes ``[U, Q]`` orthonormal; what rounding leaves of ``U^T D`` is removed by step 4);
+    2. the 2r x 2r triangular blocks are absorbed into the (small) core, in float64;
+    3. per factor: the leading left singular subspace ``W`` of the core unfolding(s) -- for a shared factor, of
+       the concatenation of its modes' unfoldings: the one basis that serves both best in the least-squares sense
+       -- by warm-started subspace iteration (``smalllinalg.dominant_left_subspace``); core and factor are
+       truncated at once (sequentially truncated HOSVD);
+    4. the new factor ``[U, Q] W`` is re-orthonormalised by one more Cholesky QR round so drift cannot add up
+       over the steps, its triangular factor absorbed into the core."""
+    dt = core.dtype
+    blocks, bases = [], []
+    for U, D in pairs:
+        r = U.shape[1]
+        Q, Rd = _orth_tall(D)                           # U^T D = 0 is the gauge condition: [U, Q] is orthonormal
+        k = r + D.shape[1]
+        blk = torch.zeros((k, k), dtype=torch.float64, device=core.device)
+        blk[:r, :r] = torch.eye(r, dtype=torch.float64, device=core.device)
+        blk[r:, r:] = Rd
+        blocks.append(blk)
+        bases.append((U, Q))
+    c64 = core.double()
+    for m, f in enumerate(mode_factor):
+        c64 = _mode_dot(c64, blocks[f], m)
+    new_factors = []
+    for f, (U, Q) in enumerate(bases):
+        modes = [m for m, g in enumerate(mode_factor) if g == f]
+        M = torch.cat([_unfold(c64, m) for m in modes], dim=1) if len(modes) > 1 else _unfold(c64, modes[0])
+        W = dominant_left_subspace(M, int(ranks[f]))
+        r = U.shape[1]
+        Wd = W.to(dt)
+        newU = U @ Wd[:r] + Q @ Wd[r:]
+        S = _tn(newU, newU)
+        eye = torch.eye(S.shape[0], dtype=S.dtype, device=S.device)
+        _note_health((S - eye).abs().max())
+        X, Rfix = gram_factor(S, shift=0.0 if dt == torch.float64 else 1e-7)
+        newU = newU @ X.to(dt)
+        T = Rfix @ W.transpose(0, 1)                     # (r_new x 2r): truncate, then the polish's triangular factor
+        for m in modes:
+            c64 = _mode_dot(c64, T, m)
+        new_factors.append(newU)
+    out = c64.to(dt)
+    inf = torch.full((), float("inf"), dtype=torch.float64, device=out.device)
+    _note_health(torch.where(torch.isfinite(out).all(), torch.zeros_like(inf), inf))
+    return out, new_factors
 
 
 def _truncated_left_basis(mat: torch.Tensor, r: int) -> torch.Tensor:
-    """The r leading left singular vectors of ``mat`` (columns).  Core unfoldings are short and wide (2r x 4r^2):
-    on the GPU in fp32 they come from the eigenvectors of the small Gram matrix ``mat mat^T`` (one GEMM + one
-    2r x 2r symmetric eigenproblem instead of a Jacobi SVD of the wide matrix).
-
-    Squaring the spectrum puts the fp32 noise floor at 3e-4 of the largest singular value.  That is harmless
-    while the r-th direction is well above it -- and wrong once the core has dead directions that the step's
-    new ones (singular values ~ the step length, 1e-3 of ||T|| and less) should replace: measured on WN18RR, half
-    of a step's change was lost in ``round()`` from epoch 16 on.  When the smallest kept eigenvalue is within
-    1e-5 of the largest, the Gram matrix is therefore accumulated in float64 (exact products of fp32 values) and
-    its eigenvectors are taken on the host (LAPACK: 15 ms for 400 x 400; rocSOLVER's float64 ``syevd`` needs
-    80 ms and its fp32 divide-and-conquer does not always converge on such spectra).  Elsewhere (CPU, float64:
-    the identity tests) the SVD itself."""
-    if mat.shape[0] <= r:
-        r = mat.shape[0]
-    if mat.is_cuda and mat.dtype == torch.float32 and mat.shape[1] >= 4 * mat.shape[0]:
-        try:
-            w, V = torch.linalg.eigh(mat @ mat.transpose(0, 1))        # ascending eigenvalues
-            if bool(torch.isfinite(V).all()) and bool(w[-r] > 1e-5 * w[-1]):
-                return V[:, -r:].flip(1)
-        except torch.linalg.LinAlgError:
-            pass
-        FALLBACKS["eigh_float64_host"] += 1
-        m64 = mat.double()
-        try:
-            w, V = _host_eigh((m64 @ m64.transpose(0, 1)).cpu())
-            if bool(torch.isfinite(V).all()):
-                return V[:, -r:].flip(1).to(device=mat.device, dtype=mat.dtype)
-        except torch.linalg.LinAlgError:
-            pass
-        FALLBACKS["svd"] += 1
+    """The r leading left singular vectors of ``mat`` (columns) by SVD: the generic ``round()`` of a tensor that
+    did not come from ``TangentVector.construct()`` (rank tuning, tests); not on the training path."""
+    r = min(r, mat.shape[0])
     U, _, _ = torch.linalg.svd(mat, full_matrices=False)
     return U[:, :r]
 
@@ -203,23 +183,23 @@ class Tucker:
         return t
 
     def round(self, rank: Sequence[int]) -> "Tucker":
-        """Best-effort rank-``rank`` approximation with orthonormal factors (truncated HOSVD)."""
+        """Best-effort rank-``rank`` approximation with orthonormal factors (truncated HOSVD).  A tensor built by
+        ``TangentVector.construct()`` (``orth_cols`` set) takes the structured, synchronisation-free path."""
+        if self.orth_cols is not None:
+            pairs = [(f[:, :k], f[:, k:]) for f, k in zip(self.factors, self.orth_cols)]
+            core, new = _round_tangent_step(self.core, pairs, list(range(len(pairs))), [int(r) for r in rank])
+            return Tucker(core, new)
         core = self.core
         qs = []
         for i, f in enumerate(self.factors):
-            q, r = _qr_thin(f, self.orth_cols[i] if self.orth_cols else 0)    # thin: (n, k), (k, k)
+            q, r = torch.linalg.qr(f)                     # thin: (n, k), (k, k)
             qs.append(q)
             core = _mode_dot(core, r, i)
         new_factors = []
         for i, q in enumerate(qs):
             u = _truncated_left_basis(_unfold(core, i), int(rank[i]))
-            f = q @ u
+            new_factors.append(q @ u)
             core = _mode_dot(core, u.transpose(0, 1), i)
-            fixed = _polish(f) if self.orth_cols else None
-            if fixed is not None:
-                f, rfix = fixed
-                core = _mode_dot(core, rfix, i)
-            new_factors.append(f)
         return Tucker(core, new_factors)
 
     def __add__(self, other: "Tucker") -> "Tucker":
@@ -270,38 +250,34 @@ class SFTucker:
     def round(self, rank: Sequence[int]) -> "SFTucker":
         """Truncated HOSVD with ONE basis for the shared modes: the leading left singular vectors of the
         concatenated shared-mode unfoldings (the subspace that serves both modes best in the least-squares
-        sense)."""
+        sense).  ``orth_cols`` set (``TangentVector.construct()``): the structured, synchronisation-free path."""
         nreg = len(self.regular_factors)
+        ns = self.num_shared_factors
+        if self.orth_cols is not None:
+            fs = self.regular_factors + [self.shared_factor]
+            pairs = [(f[:, :k], f[:, k:]) for f, k in zip(fs, self.orth_cols)]
+            core, new = _round_tangent_step(self.core, pairs, list(range(nreg)) + [nreg] * ns,
+                                            [int(rank[i]) for i in range(nreg)] + [int(rank[nreg])])
+            return SFTucker(core, new[:nreg], ns, new[nreg])
         core = self.core
         qs = []
         for i, f in enumerate(self.regular_factors):
-            q, r = _qr_thin(f, self.orth_cols[i] if self.orth_cols else 0)
+            q, r = torch.linalg.qr(f)
             qs.append(q)
             core = _mode_dot(core, r, i)
-        qe, re = _qr_thin(self.shared_factor, self.orth_cols[-1] if self.orth_cols else 0)
-        for m in range(nreg, nreg + self.num_shared_factors):
+        qe, re = torch.linalg.qr(self.shared_factor)
+        for m in range(nreg, nreg + ns):
             core = _mode_dot(core, re, m)
         new_regular = []
         for i, q in enumerate(qs):
             u = _truncated_left_basis(_unfold(core, i), int(rank[i]))
-            f = q @ u
+            new_regular.append(q @ u)
             core = _mode_dot(core, u.transpose(0, 1), i)
-            fixed = _polish(f) if self.orth_cols else None
-            if fixed is not None:
-                f, rfix = fixed
-                core = _mode_dot(core, rfix, i)
-            new_regular.append(f)
-        cat = torch.cat([_unfold(core, m) for m in range(nreg, nreg + self.num_shared_factors)], dim=1)
+        cat = torch.cat([_unfold(core, m) for m in range(nreg, nreg + ns)], dim=1)
         ue = _truncated_left_basis(cat, int(rank[nreg]))
-        for m in range(nreg, nreg + self.num_shared_factors):
+        for m in range(nreg, nreg + ns):
             core = _mode_dot(core, ue.transpose(0, 1), m)
-        fe = qe @ ue
-        fixed = _polish(fe) if self.orth_cols else None
-        if fixed is not None:
-            fe, rfix = fixed
-            for m in range(nreg, nreg + self.num_shared_factors):
-                core = _mode_dot(core, rfix, m)
-        return SFTucker(core, new_regular, self.num_shared_factors, fe)
+        return SFTucker(core, new_regular, ns, qe @ ue)
 
     def __rmul__(self, scalar) -> "SFTucker":
         return SFTucker(scalar * self.core, list(self.regular_factors), self.num_shared_factors, self.shared_factor)

@@ -34,7 +34,7 @@ def test_train_py_short_run(tmp_path, capsys, mode, optim):
         assert all(0.0 <= x <= 1.0 for x in m.val + m.test)
     # (no claim on the trajectory here: with the README recipe the loss is dominated by 1e-4 * ||T||^2 at
     # unit-normalised steps of length 2000 in the first epochs; see test_descends_with_a_small_step)
-    # the retraction keeps the factors orthonormal (fp32 QR + SVD)
+    # the retraction keeps the factors orthonormal (fp32 Cholesky QR + float64 subspace iteration)
     for k, w in state.model.items():
         if k.endswith(".weight"):
             assert _orthonormal(w) < 5e-5, k
@@ -102,57 +102,134 @@ def test_one_full_epoch_at_the_readme_rank(tmp_path, capsys):
     assert len(state.metrics.mrr.val) == 1
 
 
-def test_core_basis_survives_an_eigensolver_failure(monkeypatch):
-    """``round()`` takes the left basis of a core unfolding from ``eigh`` of its Gram matrix: in fp32 on the GPU
-    while the kept directions are well above the noise floor of the squared spectrum, in float64 on the host
-    otherwise or when rocSOLVER's divide-and-conquer does not converge (seen after 7 epochs of small-step RSGD on
-    WN18RR), by SVD as the last resort."""
-    from r_tucker_amd import tucker
+def test_gram_factor_kernel_against_torch():
+    """rtk_gram_factor_f64 (one workgroup per matrix: equilibration, shift, blocked Cholesky, the inverse from the
+    same sweep, transposed outputs) vs torch in float64."""
+    from r_tucker_amd import smalllinalg as sl
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for k, nb in ((1, 2), (7, 3), (32, 1), (33, 2), (64, 1), (200, 3), (256, 2)):
+        W = torch.randn(nb, 2 * k + 3, k, device="cuda", dtype=torch.float64, generator=g)
+        W = W * torch.logspace(0, -4, k, device="cuda", dtype=torch.float64)          # badly scaled columns
+        S = W.transpose(1, 2) @ W
+        eye = torch.eye(k, device="cuda", dtype=torch.float64)
+        X, R = sl.gram_factor(S, shift=0.0, equilibrate=False)
+        ref = torch.linalg.cholesky(S).transpose(1, 2)
+        assert (R - ref).abs().max().item() <= 1e-9 * ref.abs().max().item(), k
+        assert (R.tril(-1).abs().max().item() == 0 and X.tril(-1).abs().max().item() == 0) or k == 1
+        X, R = sl.gram_factor(S)                                                       # equilibrated + 1e-13 shift
+        Q = W @ X
+        assert (Q.transpose(1, 2) @ Q - eye).abs().max().item() < 1e-9, k
+        assert (Q @ R - W).abs().max().item() <= 1e-9 * W.abs().max().item(), k
+        inv = sl.spd_inverse(S, 1e-3)
+        A = S + 1e-3 * S.diagonal(dim1=1, dim2=2).sum(-1)[:, None, None] * eye
+        assert (inv @ A - eye).abs().max().item() < 1e-8, k
+    # numerically singular and zero matrices: finite output, no status (pivots floored / zeros)
+    W = torch.randn(40, 24, device="cuda", dtype=torch.float64, generator=g)
+    W[:, 5] = W[:, 4]
+    X, R = sl.gram_factor(W.T @ W)
+    assert torch.isfinite(X).all() and torch.isfinite(R).all()
+    X, R = sl.gram_factor(torch.zeros(9, 9, device="cuda", dtype=torch.float64))
+    assert X.abs().max().item() == 0 and R.abs().max().item() == 0
+
+
+def test_subspace_iteration_on_device_keeps_new_directions():
+    """Dead directions in the old block, new directions 1e-4 of the largest and exactly orthogonal to the old row
+    space: round 2's fp32 ``eigh`` of the squared spectrum could not tell them from noise (half of every step was
+    lost from epoch 16 on) and its float64 fallback went through the host; the unsquared float64 iteration keeps
+    them, on the device, without a synchronisation."""
+    from r_tucker_amd import smalllinalg as sl
     g = torch.Generator(device="cuda").manual_seed(5)
-    flat = torch.randn(40, 1600, device="cuda", generator=g)
-    want = tucker._truncated_left_basis(flat, 12)
-    real = torch.linalg.eigh
-    seen = []
-
-    def device_fails(a, *args, **kw):
-        seen.append((a.device.type, a.dtype))
-        if a.is_cuda:
-            raise torch.linalg.LinAlgError("forced: did not converge")
-        return real(a, *args, **kw)
-
-    def same_subspace(got, ref, tol):
-        assert got.is_cuda and got.dtype == torch.float32
-        assert (got.T @ got - torch.eye(got.shape[1], device="cuda")).abs().max().item() < 1e-5
-        assert (got @ got.T - ref @ ref.T).abs().max().item() < tol
-
-    monkeypatch.setattr(torch.linalg, "eigh", device_fails)
-    tucker.FALLBACKS.clear()
-    same_subspace(tucker._truncated_left_basis(flat, 12), want, 1e-3)
-    assert seen == [("cuda", torch.float32), ("cpu", torch.float64)] and dict(tucker.FALLBACKS) == {"eigh_float64_host": 1}
-
-    def always_fails(a, *args, **kw):
-        raise torch.linalg.LinAlgError("forced")
-
-    monkeypatch.setattr(torch.linalg, "eigh", always_fails)
-    same_subspace(tucker._truncated_left_basis(flat, 12), want, 1e-3)
-    assert tucker.FALLBACKS["svd"] == 1
-    monkeypatch.setattr(torch.linalg, "eigh", real)
-
-    # dead directions in the old block, new directions 1e-4 of the largest: fp32 on the squared spectrum cannot
-    # tell them from noise, the float64 path keeps the new ones
-    tucker.FALLBACKS.clear()
-    r = 12
-    Va = torch.linalg.qr(torch.randn(1600, 2 * r, device="cuda", generator=g))[0]
-    sv = torch.cat([torch.logspace(4, 3, r - 3, device="cuda"), torch.full((3,), 1e-6, device="cuda")])
-    A = (torch.linalg.qr(torch.randn(r, r, device="cuda", generator=g))[0] * sv) @ Va[:, :r].T
-    Bm = torch.zeros(r, 1600, device="cuda")
-    Bm[:3] = 1.0 * Va[:, r:r + 3].T                                   # three new directions with singular value 1
+    r, m = 12, 1600
+    Va = torch.linalg.qr(torch.randn(m, 2 * r, device="cuda", dtype=torch.float64, generator=g))[0]
+    sv = torch.cat([torch.logspace(4, 3, r - 3, device="cuda", dtype=torch.float64),
+                    torch.full((3,), 1e-6, device="cuda", dtype=torch.float64)])
+    A = (torch.linalg.qr(torch.randn(r, r, device="cuda", dtype=torch.float64, generator=g))[0] * sv) @ Va[:, :r].T
+    Bm = torch.zeros(r, m, device="cuda", dtype=torch.float64)
+    Bm[:3] = Va[:, r:r + 3].T
     mat = torch.cat([A, Bm])
-    got = tucker._truncated_left_basis(mat, r)
-    assert tucker.FALLBACKS["eigh_float64_host"] == 1
-    kept = (got.T @ mat).norm() ** 2
-    best = torch.linalg.svdvals(mat.double())[:r].pow(2).sum()
-    assert abs(kept.item() - best.item()) <= 1e-6 * best.item()
-    new_energy = (got[r:r + 3].norm() ** 2).item()                     # the three new coordinates are in the basis
-    assert new_energy > 2.9
-    tucker.FALLBACKS.clear()
+    W = sl.dominant_left_subspace(mat, r)
+    assert (W.T @ W - torch.eye(r, device="cuda", dtype=torch.float64)).abs().max().item() < 1e-9
+    kept = ((W.T @ mat) ** 2).sum().item()
+    best = (torch.linalg.svdvals(mat)[:r] ** 2).sum().item()
+    assert abs(kept - best) <= 1e-6 * best
+    assert (W[r:r + 3] ** 2).sum().item() > 2.999
+
+
+def test_structured_round_at_the_wn18rr_shape():
+    """The retraction of a tangent step at rank (10,200,200), 40 943 entities, fp32 on the device: new factors
+    orthonormal, truncation error no worse than the generic QR + SVD path's."""
+    import r_tucker_amd as rt
+    from r_tucker_amd.riemannian import TuckerRiemannian as geo
+    from r_tucker_amd.tucker import Tucker, read_health
+    torch.manual_seed(1)
+    model = rt.AsymmetricR_TuckER((40943, 22), (10, 200, 200))
+    model.init()
+    with torch.no_grad():
+        model.core.mul_(50.0)
+    model.cuda()
+    x = Tucker(model.core.data, [model.R.weight.data, model.S.weight.data, model.O.weight.data])
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Z = Tucker(torch.randn(10, 200, 200, device="cuda", generator=g),
+               [torch.linalg.qr(torch.randn(n, k, device="cuda", generator=g))[0] for n, k in ((22, 10), (40943, 200), (40943, 200))])
+    xi = geo.project(x, Z)
+    xi = (x.norm().item() * 0.05 / xi.norm().item()) * xi
+    moved = (xi + geo.TangentVector(x)).construct()
+    read_health()
+    y = moved.round((10, 200, 200))
+    pre = max(read_health().values())
+    assert pre < 1e-2                                                     # before the polish
+    for w in y.factors:
+        assert _orthonormal(w) < 5e-5
+    y2 = Tucker(moved.core, moved.factors).round((10, 200, 200))
+
+    def err(t):       # || t - moved || through Gram contractions of the difference (no dense tensor)
+        d = t + ((-1.0) * moved)
+        return d.norm().item()
+
+    assert err(y) <= 1.01 * err(y2) + 1e-4 * moved.norm().item(), (err(y), err(y2))
+
+
+def test_captured_step_equals_eager_steps(tmp_path):
+    """The HIP-graph replay of the optimizer step (graphstep.CapturedTrainStep) against the same steps run
+    eagerly from the same start: same batches, same learning-rate / regulariser schedule -> same parameters."""
+    import r_tucker_amd as rt
+    from r_tucker_amd import driver, graphstep
+    from r_tucker_amd.data import Data, KG_dataset
+    from r_tucker_amd.model.asymmetric.optim import RSGDwithMomentum
+    data = Data(os.path.join(ROOT, "data", "WN18RR") + "/", reverse=True)
+    train_set = KG_dataset(data, data.train_data, label_smoothing=0.1)
+    flt = rt.DeviceFilter(train_set, "cuda")
+    rank = (6, 24, 24)
+
+    def run(enabled):
+        graphstep.ENABLED = enabled
+        torch.manual_seed(5)
+        model = rt.AsymmetricR_TuckER((len(data.entities), len(data.relations)), rank)
+        model.init()
+        model.cuda()
+        params = torch.nn.ParameterList([model.core, model.S.weight, model.R.weight, model.O.weight])
+        opt = RSGDwithMomentum(params, rank, 50.0, 0.8)
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.5)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        losses = []
+        for epoch in range(2):
+            step = driver._captured_step(model, opt, flt, 512, 0.1)
+            step.begin_epoch(1e-9 * (epoch + 1))
+            for b in range(5):
+                step.run(torch.randint(0, flt.features.shape[0], (512,), device="cuda", generator=gen))
+            losses.append(step.totals())
+            sched.step()
+        replays = step.replays
+        return [p.detach().clone() for p in params], losses, replays
+
+    try:
+        eager, le, n0 = run(False)
+        graph, lg, n1 = run(True)
+    finally:
+        graphstep.ENABLED = True
+    assert n0 == 0 and n1 == 10 - graphstep.EAGER_STEPS
+    for a, b in zip(eager, graph):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+    for (a0, a1), (b0, b1) in zip(le, lg):
+        assert abs(a0 - b0) <= 1e-5 * abs(a0) and abs(a1 - b1) <= 1e-4 * abs(a1)

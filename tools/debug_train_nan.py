@@ -93,16 +93,15 @@ for epoch in range(1, max_epochs + 1):
         upd = ((want - old).norm() / want.norm()).item()
         if rel > 0.5 * max(upd, 1e-6) and rel > 1e-4:
             print(f"RETRACTION MISMATCH at epoch {epoch} batch {b} step {step}: |round(x - lr d) - (x - lr d)| / |.| = {rel:.3e}, "
-                  f"update size {upd:.3e}, fallbacks {dict(_tk.FALLBACKS)}")
+                  f"update size {upd:.3e}, health {_tk.read_health(clear=False)}")
             print("   core spectrum after:", core_spectrum(model.core.data))
             sys.exit(0)
         if not finite("params after step", model.core.data, model.R.weight.data, model.S.weight.data, model.O.weight.data):
             print(f"first failure in step: epoch {epoch} batch {b} step {step}; loss {opt.loss.item()} grad norm {gn.item()}")
             sys.exit(0)
         cur = opt.loss.item()
-        hist.append((step, cur, gn.item(), dict(_tk.FALLBACKS), max(x.abs().max().item() for x in d.delta_factors),
+        hist.append((step, cur, gn.item(), _tk.read_health(), max(x.abs().max().item() for x in d.delta_factors),
                      d.delta_core.abs().max().item()))
-        _tk.FALLBACKS.clear()
         if prev_loss is not None and cur > prev_loss + 0.05:
             print(f"LOSS JUMP at epoch {epoch} batch {b} step {step}: {prev_loss:.4f} -> {cur:.4f}")
             for h in hist[-6:]:
