@@ -74,11 +74,22 @@ def read_health(device=None, clear: bool = True):
     """Largest pre-polish orthonormality error since the last call (``inf``: something was not finite); one sync."""
     out = {}
     for k, v in HEALTH.items():
-        if device is None or k == torch.device(device):
+        if device is None or (k.type == torch.device(device).type and torch.device(device).index in (None, k.index)):
             out[str(k)] = float(v)
             if clear:
                 v.zero_()
     return out
+
+
+_CHECK = __import__("os").environ.get("R_TUCKER_AMD_CHECK_FINITE", "0") == "1"
+
+
+def _dbg(what: str, t: torch.Tensor) -> None:
+    """``R_TUCKER_AMD_CHECK_FINITE=1`` (one sync per call): name the first non-finite intermediate of the retraction."""
+    if _CHECK and not bool(torch.isfinite(t).all()):
+        bad = (~torch.isfinite(t)).nonzero()
+        raise FloatingPointError(f"retraction: {what} of shape {tuple(t.shape)} has {bad.shape[0]} non-finite entries, "
+                                 f"first at {bad[0].tolist()}; finite abs max {t[torch.isfinite(t)].abs().max().item() if bad.shape[0] < t.numel() else 'n/a'}")
 
 
 def _orth_tall(D: torch.Tensor):
@@ -88,9 +99,14 @@ def _orth_tall(D: torch.Tensor):
     host synchronisation).  rocSOLVER's Householder ``geqrf`` spends 90 ms on a 40 943 x 400 factor; this is
     four chip-filling GEMMs.  A column of zeros stays zero (its row of R is zero)."""
     sh = 3e-6 if D.dtype == torch.float32 else None          # fp32 Gram: shift at its rounding noise
-    X1, R1 = gram_factor(_tn(D, D), shift=sh)
+    S1 = _tn(D, D)
+    _dbg("Gram matrix of the new factor block", S1)
+    X1, R1 = gram_factor(S1, shift=sh)
+    _dbg("first Cholesky-QR round: X", X1)
     Q = D @ X1.to(D.dtype)
+    _dbg("first Cholesky-QR round: Q", Q)
     X2, R2 = gram_factor(_tn(Q, Q), shift=None if sh is None else 1e-6)
+    _dbg("second Cholesky-QR round: X", X2)
     return Q @ X2.to(D.dtype), R2 @ R1
 
 
@@ -127,7 +143,9 @@ def _round_tangent_step(core: torch.Tensor, pairs, mode_factor, ranks):
     for f, (U, Q) in enumerate(bases):
         modes = [m for m, g in enumerate(mode_factor) if g == f]
         M = torch.cat([_unfold(c64, m) for m in modes], dim=1) if len(modes) > 1 else _unfold(c64, modes[0])
+        _dbg(f"core unfolding of factor {f}", M)
         W = dominant_left_subspace(M, int(ranks[f]))
+        _dbg(f"subspace basis of factor {f}", W)
         r = U.shape[1]
         Wd = W.to(dt)
         newU = U @ Wd[:r] + Q @ Wd[r:]
@@ -135,6 +153,7 @@ def _round_tangent_step(core: torch.Tensor, pairs, mode_factor, ranks):
         eye = torch.eye(S.shape[0], dtype=S.dtype, device=S.device)
         _note_health((S - eye).abs().max())
         X, Rfix = gram_factor(S, shift=0.0 if dt == torch.float64 else 1e-7)
+        _dbg(f"polish of factor {f}: X", X)
         newU = newU @ X.to(dt)
         T = Rfix @ W.transpose(0, 1)                     # (r_new x 2r): truncate, then the polish's triangular factor
         for m in modes:
