@@ -21,6 +21,7 @@ namespace {
 constexpr int NB = 32;          // block width
 constexpr int KMAX = 256;       // largest matrix (LDS: two k x 32 panels + two 32 x 32 blocks)
 constexpr int NT = 1024;
+constexpr int GRP = 2;        // global read-modify-writes in flight per thread in the trailing updates (8 spills)
 
 // S: k x k Gram matrix.  A = D^-1 S D^-1 + (shift_diag + shift_trace * trace(S)) I with D = sqrt(diag S) when
 // `equil` (else D = I) is factored A = L L^T; outputs (upper triangular)  R = L^T D  and  X = D^-1 L^-T, so that for
@@ -144,12 +145,12 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
         // Read-modify-writes of global memory in groups of eight: the loads of a group are in flight together
         // (one after the other, each waiting for the previous store, they were 80 % of the kernel).
         // A[i, c2] -= sum_m pan[i][m] pan[c2][m],  j0 + w <= c2 <= i
-        for (int e0 = t; e0 < below * below; e0 += 8 * NT) {
-            double old[8], s8[8];
-            size_t at[8];
-            bool on[8];
+        for (int e0 = t; e0 < below * below; e0 += GRP * NT) {
+            double old[GRP], s8[GRP];
+            size_t at[GRP];
+            bool on[GRP];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GRP; ++u) {
                 const int e = e0 + u * NT;
                 const int i = e / below, c2 = e - i * below;
                 on[u] = e < below * below && c2 <= i;
@@ -163,16 +164,16 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
                 s8[u] = sacc;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < GRP; ++u)
                 if (on[u]) Lo[at[u]] = old[u] - s8[u];
         }
         // B[i, c] -= sum_m pan[i][m] * B[j0 + m, c],  c < left
-        for (int e0 = t; e0 < below * left; e0 += 8 * NT) {
-            double old[8], s8[8];
-            size_t at[8];
-            bool on[8];
+        for (int e0 = t; e0 < below * left; e0 += GRP * NT) {
+            double old[GRP], s8[GRP];
+            size_t at[GRP];
+            bool on[GRP];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GRP; ++u) {
                 const int e = e0 + u * NT;
                 const int i = e / left, c = e - i * left;
                 on[u] = e < below * left;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
                 s8[u] = sacc;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < GRP; ++u)
                 if (on[u]) Ti[at[u]] = old[u] - s8[u];
         }
         __syncthreads();

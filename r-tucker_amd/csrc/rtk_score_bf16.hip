@@ -307,7 +307,7 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
     const int B = (int)batch, N = (int)n_local;
     // 8-wave workgroups (256 entities share a staged query tile) once the problem fills the chip that way
     static const bool narrow = getenv("RTK_BF16_NARROW") != nullptr;   // A/B: 4-wave workgroups, two per CU
-    const bool wide = !narrow && ks > 16 && rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256;
+    const bool wide = !narrow && ks > 16 && ((flags & RTK_SCORE_DEEP_K) || rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256);
 #define RTK_KS(K_, W_) case K_: rc = launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, obf, st); break;
     int rc = RTK_OK;
     switch (ks) {

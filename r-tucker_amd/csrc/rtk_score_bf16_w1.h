@@ -173,13 +173,13 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
             chain(later_t{}, i, accB0, accB1, accA0, accA1);
             chain(later_t{}, i + 1, accA0, accA1, accB0, accB1);
         }
-        epilogue_begin(mt0 + cnt - 1);
         if (i < cnt) {
             chain(later_t{}, i, accB0, accB1, accA0, accA1);
             epilogue_begin(mt0 + cnt - 1);
 #pragma unroll
             for (int pc = 0; pc < 64; ++pc) piece(accB0, accB1, pc);
         } else {
+            epilogue_begin(mt0 + cnt - 1);
 #pragma unroll
             for (int pc = 0; pc < 64; ++pc) piece(accA0, accA1, pc);
         }

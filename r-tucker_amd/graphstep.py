@@ -25,6 +25,12 @@ from . import tucker as _tucker
 
 ENABLED = os.environ.get("R_TUCKER_AMD_GRAPH", "1") == "1"
 EAGER_STEPS = 2
+# Replays the host may run ahead of the GPU.  A replay is ~700 kernel nodes and takes the GPU ~25 ms but the host
+# ~2 ms to enqueue: unthrottled, a whole epoch (169 replays, ~120 000 packets) sits in the queue.  Free-running
+# replays produced NaN parameters once in ~2 000 steps on this stack (ROCm 7.2, torch 2.10) while the same steps run
+# eagerly, or replayed with a synchronisation after each, did not (tools/debug_graph_nan.py) --
+# so the host waits for replay n - IN_FLIGHT before it launches replay n (an event wait, no device idle time).
+IN_FLIGHT = int(os.environ.get("R_TUCKER_AMD_GRAPH_IN_FLIGHT", "2"))
 
 
 class CapturedTrainStep:
@@ -42,6 +48,7 @@ class CapturedTrainStep:
         self.graph = None
         self.eager_done = 0
         self.replays = 0
+        self._events = []
 
     # one step on the ids currently in self.ids (runs eagerly or under capture: same code)
     def _body(self):
@@ -64,8 +71,7 @@ class CapturedTrainStep:
             raise RuntimeError(f"captured step is for batches of {self.B} items, got {ids.numel()}")
         self.ids.copy_(ids)
         if self.graph is not None:
-            self.graph.replay()
-            self.replays += 1
+            self._replay()
             return
         if self.eager_done < EAGER_STEPS or not ENABLED or not getattr(self.opt, "capturable", False):
             self._body()
@@ -76,8 +82,23 @@ class CapturedTrainStep:
         with torch.cuda.graph(g):
             self._body()
         self.graph = g              # (the capture itself executed nothing: replay it for this batch)
-        g.replay()
+        self._replay()
+
+    def _replay(self):
+        if IN_FLIGHT > 0 and len(self._events) >= IN_FLIGHT:
+            self._events.pop(0).synchronize()
+        self.graph.replay()
         self.replays += 1
+        if IN_FLIGHT > 0:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._events.append(ev)
+
+    def drop_graph(self):
+        """Forget the capture (the next steps run eagerly, two of them before a new capture if still enabled)."""
+        self.graph = None
+        self._events = []
+        self.eager_done = 0
 
     def totals(self):
         """(sum of losses, sum of gradient norms) over the steps since ``begin_epoch`` -- one synchronisation."""

@@ -131,6 +131,12 @@ def main():
     budget = args.minutes * 60.0
     epoch = epoch0
     epoch_times = []
+    from r_tucker_amd import graphstep
+
+    def snapshot():
+        return [p.detach().clone() for p in opt.param_groups[0]["params"]], (regulizer.val, regulizer.cur_step, regulizer._moves)
+
+    good = snapshot()
     while epoch < n_epochs:
         if args.max_epochs is not None and epoch - epoch0 >= args.max_epochs:
             break
@@ -160,9 +166,26 @@ def main():
         for g in opt.param_groups:
             g["lr"] = lr0 * gamma ** epoch
         epoch_times.append(time.time() - te)
-        if not math.isfinite(train_loss):
-            log({"event": "non_finite_loss", "epoch": epoch})
-            break
+        ok = math.isfinite(train_loss) and all(bool(torch.isfinite(p).all()) for p in opt.param_groups[0]["params"])
+        if not ok:
+            # restore the last good epoch and go on WITHOUT the HIP graph (free-running replays)
+            log({"event": "non_finite_state", "epoch": epoch, "graph_was_enabled": graphstep.ENABLED, "action": "restore + eager"})
+            if not graphstep.ENABLED:
+                break                                   # eager steps produced it: a real numerical problem, stop
+            with torch.no_grad():
+                for p, g in zip(opt.param_groups[0]["params"], good[0]):
+                    p.copy_(g)
+            regulizer.val, regulizer.cur_step, regulizer._moves = good[1]
+            opt._prev = None
+            graphstep.ENABLED = False
+            cap = getattr(opt, "_rtk_captured", None)
+            if cap is not None:
+                cap[1].drop_graph()
+            epoch -= 1
+            for g in opt.param_groups:
+                g["lr"] = lr0 * gamma ** epoch
+            continue
+        good = snapshot()
     save(epoch)
     log({"event": "lease_end", "epoch": epoch, "done": epoch >= n_epochs, "wall_s": time.time() - t_start,
          "checkpoint_bytes": os.path.getsize(ckpt_path)})
