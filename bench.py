@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- 1-vs-N triples scored / s of the HIP scoring path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Both forms work for N > 1: started without a torch.distributed environment, `--gpus N` launches the second form
+itself (N fresh child processes, one rank per GPU over RCCL, before this process has touched a GPU) and exits
+with the children's status; rank 0's JSON line is the only thing on stdout.
 
 A "step" = one pass of the whole hot path (query vectors + 1-vs-all scores + sigmoid)
 over one batch of synthetic (h, r) queries, operands already resident in HBM.
@@ -86,6 +90,37 @@ def cpu_baseline(gen, n_ent, n_rel, B, rank, pool, budget_s=15.0):
                       f"oracle/score_oracle.py::score_ref"}
 
 
+def launch_children(argv, n):
+    """`python bench.py --gpus N` with no torch.distributed environment: start N ranks under torch.distributed.run
+    (fresh processes: this one has not initialised a GPU and never will) and hand back their exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the hosts only support dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(args):
+    """Hidden `--launcher-selftest` (CPU, gloo): what the children of `launch_children` do up to the first
+    collective -- rendezvous, one all-reduce, ONE JSON line from rank 0, exit status -- without a GPU."""
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=2))
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "sum_of_ranks_plus_one": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +143,13 @@ def main():
                     help="multi-GPU: run the all-gather of step i before step i+1 starts (default: it overlaps the next step's kernels)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-GPU code path (process group, collectives) with however many ranks there are, even one")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_children(sys.argv[1:], args.gpus))
+    if args.launcher_selftest:
+        return launcher_selftest(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,7 +239,7 @@ def main():
     ft_fn = lib.rtk_query_vectors_from_tables_bf16 if bf16 else lib.rtk_query_vectors_from_tables_f32
     tb_fn = lib.rtk_relation_tables_bf16 if bf16 else lib.rtk_relation_tables_f32
     sp_fn = lib.rtk_score_packed_bf16 if bf16 else lib.rtk_score_packed_f32
-    need_v = args.exact or split1
+    need_v = args.exact or split1 or (world == 1 and not bf16)     # (the extra exact-fp32 leg of the N = 1 line)
     v = torch.empty((B, c), dtype=torch.float32, device=dev) if need_v else None
     tables = tws = None
     if cached:
@@ -209,7 +250,7 @@ def main():
     qlo, qhi = min(rank * B_loc, B), min((rank + 1) * B_loc, B)
     v_all = torch.zeros((world * B_loc, c), dtype=torch.float32, device=dev) if split1 else None
 
-    def stage1(h, r):
+    def stage1(h, r, cached=cached, want_v=args.exact):
         """query vectors of the batch -> packed planes in qp (and/or fp32 v)"""
         if split1:
             nq = qhi - qlo
@@ -226,7 +267,7 @@ def main():
             if not args.exact:
                 _lib.check(lib.rtk_pack_query_vectors(v_all.data_ptr(), B, c, dcode, qp.data_ptr(), sp), "rtk_pack_query_vectors")
             return v_all
-        vo = v.data_ptr() if args.exact else None
+        vo = v.data_ptr() if want_v else None
         qo = None if args.exact else qp.data_ptr()
         if cached:
             _lib.check(ft_fn(tables.data_ptr(), n_rel, b, c, S.data_ptr(), n_ent, r.data_ptr(), h.data_ptr(), B, vo, qo,
@@ -236,15 +277,15 @@ def main():
                              vo, qo, ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors")
         return v
 
-    def step_local(i, ev=None, out=out):
+    def step_local(i, ev=None, out=out, cached=cached, exact=args.exact):
         h, r = pool[i % len(pool)]
         if cached and i % EVAL_BATCHES == 0:     # a new "evaluation pass": the parameters may have changed
             _lib.check(tb_fn(core.data_ptr(), a, b, c, R.data_ptr(), n_rel, tables.data_ptr(), tws.data_ptr(), tws.numel(), sp),
                        "rtk_relation_tables")
-        vv = stage1(h, r)
+        vv = stage1(h, r, cached, exact)
         if ev:
             ev[0].record(stream)
-        if args.exact:
+        if exact:
             _lib.check(lib.rtk_score_f32(vv.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch,
                                          _lib.RTK_SCORE_SIGMOID, sp), "rtk_score_f32")
         else:
@@ -319,6 +360,26 @@ def main():
 
     events = [e for e in events if e is not None]
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    # N = 1: the two figures the headline leaves out -- the step with the relation tables
+    # rebuilt for EVERY batch (the reference's per-batch semantics), and the exact-fp32 MFMA score kernel
+    extras = {}
+    if world == 1 and not use_dist and not args.exact:
+        n_x = max(10, min(args.steps, 200))
+        if cached:
+            for i in range(10):
+                step_local(i, cached=False)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(n_x):
+                step_local(i, cached=False)
+            barrier()
+            extras["per_batch_ms_per_step"] = (time.perf_counter() - t1) / n_x * 1e3
+        if not bf16 and c <= 512:
+            ex = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(12)]
+            for e2 in ex:
+                step_local(0, e2, cached=cached, exact=True)
+            barrier()
+            extras["exact_f32_kernel_ms"] = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ex[2:]]))
     gather_ms = None
     if use_dist:      # the exchange on its own (in the timed loop it runs beside the next step's kernels)
         ge = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(10)]
@@ -335,7 +396,7 @@ def main():
     # HBM bytes per launch: NOT measured by this run -- taken from the committed rocprofv3 PMC passes
     # (profiles/*_traffic.json, collected by tools/profile_round.sh) when they are for this workload
     traffic = traffic_source = None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r03_c5_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tj = json.load(f)
@@ -358,6 +419,7 @@ def main():
                    "stage1": "batch split over ranks + all-gather of the query vectors" if split1 else "on every rank",
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
         "scores_per_s": args.steps * B * n_ent / dt,
+        **extras,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ("score_bf16_kernel" if bf16 else "score_ws_kernel") if not args.exact else "gemm_f32_kernel",

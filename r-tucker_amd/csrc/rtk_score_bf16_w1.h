@@ -17,7 +17,12 @@
 //     fragments of tile i+1 are prefetched in the last gaps of chain i.  (Round 2: store, barrier, fragment reads
 //     between two chains = a bubble of one LDS round trip + barrier skew per tile.)
 //   * no accumulator merge (one dependent chain per B block: same MFMA rate, MI355X_MICROARCH.md), accumulators
-//     swap roles between tiles (no copies), the 32 store offsets of a lane are computed once per unit.
+//     swap roles between tiles (no copies).
+//   * TRANSPOSED product: the entity fragments are the MFMA's A operand and the query tile its B operand, so a
+//     lane of the 32 x 32 result holds ONE query (column) and 16 entities in four runs of 4 consecutive ones =
+//     four 16-byte stores into that query's score row (rows start on 128-byte boundaries: the four runs of the two
+//     lane halves make one full line) instead of sixteen 4-byte stores, and ONE store offset per lane (the runs are
+//     immediate offsets).  Only the matrix's last, ragged entity tile takes 4-byte stores.
 #pragma once
 #include "rtk_common.h"
 #include "rtk_pack.h"
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
         const int ntile = (int)(lin / tq), mt0 = qb0 + (int)(lin % tq);
         const int cnt = (int)min((int64_t)(qb0 + tq - mt0), lin_end - lin);
         lin += cnt;
-        const int jb = ntile * 256 + wave * 64 + r;        // entity of B block 0 (block 1: + 32)
+        const int jb = ntile * 256 + wave * 64 + r;        // entity row of this lane in block 0 (block 1: + 32)
 
         u32x4 stg[NLD];
         auto stage_load_one = [&](int mt, int i) {
@@ -87,17 +92,12 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
                 Bf[rb][ks] = x;
             }
         }
-        // store offsets of this lane, relative to the first row of a query tile: value e of an accumulator is
-        // row 8 (e / 4) + 4 h + e % 4, column = the lane's entity.  Out-of-range columns get the buffer's
-        // out-of-bounds offset (the store is dropped); rows past B are cut by the descriptor's size.
-        unsigned voff[2][16];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = 8 * (e >> 2) + 4 * h + (e & 3);
-                voff[rb][e] = (jb + 32 * rb < N) ? (unsigned)(row * ld4 + (jb + 32 * rb) * 4) : 0x80000000u;
-            }
+        // Store offset of this lane relative to the first row of a query tile: the lane's query is row r, its
+        // entities are ntile * 256 + wave * 64 + 32 rb + 8 g + 4 h + {0..3} for block rb, run g.  Rows past B are
+        // cut by the descriptor's size; columns past N only exist in the last entity tile (slow path below).
+        const int ecol = ntile * 256 + wave * 64 + 4 * h;              // first entity of run (rb = 0, g = 0)
+        const unsigned voff = (unsigned)(r * ld4 + ecol * 4);
+        const bool full = ntile * 256 + 256 <= N;                       // uniform: every column of this tile exists
 
 #pragma unroll
         for (int i = 0; i < NLD; ++i) stage_store_one(0, i);
@@ -111,20 +111,37 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
                                                     (unsigned)(rows * ld_out * 4), 0x00020000);
         };
         float ep_d = 1.f;
-        // piece pc of the 64 of a finished tile: values (rb = pc / 32, e = (pc % 32) / 2), exp half then
-        // reciprocal half + store
-        auto piece = [&](const f32x16 &z0, const f32x16 &z1, int pc) {
+        // piece pc of the 64 of a finished tile: value (rb = pc / 32, e = (pc % 32) / 2): exp half, then reciprocal
+        // half (the probability replaces the logit in its accumulator register) and, behind every fourth value, the
+        // 16-byte store of the run
+        auto piece = [&](f32x16 &z0, f32x16 &z1, int pc) {
             const int rb = pc >> 5, e = (pc & 31) >> 1;
-            const float z = rb ? z1[e] : z0[e];
+            f32x16 &zz = rb ? z1 : z0;
             if ((pc & 1) == 0) {
-                if (SIGMOID == 2) ep_d = __builtin_amdgcn_exp2f(z * -1.4426950408889634f);
-                else if (SIGMOID == 1) ep_d = 1.0f + expf(-z);
-                else ep_d = z;
+                if (SIGMOID == 2) ep_d = __builtin_amdgcn_exp2f(zz[e] * -1.4426950408889634f);
+                else if (SIGMOID == 1) ep_d = 1.0f + expf(-zz[e]);
+                else ep_d = zz[e];
             } else {
                 float pv = ep_d;
                 if (SIGMOID == 2) pv = __builtin_amdgcn_rcpf(1.0f + ep_d);
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, voff[rb][e], 0, NTS ? 2 : 0);
+                zz[e] = pv;
+                if ((e & 3) == 3) {
+                    const int g = e >> 2;
+                    const unsigned o = voff + (unsigned)(rb * 128 + g * 32);
+                    if (full) {
+                        const u32x4 q = {__builtin_bit_cast(unsigned, zz[4 * g]), __builtin_bit_cast(unsigned, zz[4 * g + 1]),
+                                         __builtin_bit_cast(unsigned, zz[4 * g + 2]), __builtin_bit_cast(unsigned, zz[4 * g + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(q, ers, o, 0, NTS ? 2 : 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool in = ecol + rb * 32 + g * 8 + q < N;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz[4 * g + q]), ers,
+                                                                  in ? o + 4u * q : 0x80000000u, 0, 0);
+                        }
+                    }
+                }
             }
         };
 
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
         }
         // one chain: tile i accumulates in (x0, x1) while the finished tile i - 1 in (y0, y1) is turned into
         // probabilities and stored
-        auto chain = [&](auto first_tag, int i, f32x16 &x0, f32x16 &x1, const f32x16 &y0, const f32x16 &y1) {
+        auto chain = [&](auto first_tag, int i, f32x16 &x0, f32x16 &x1, f32x16 &y0, f32x16 &y1) {
             constexpr bool FIRST = decltype(first_tag)::value;     // the unit's first tile: nothing to store yet
             const int cur = i % 3, nxt = (i + 1) % 3;
             const bool more = i + 1 < cnt, more2 = i + 2 < cnt;
@@ -153,12 +170,12 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
                 // next fragment: of this tile, or (last PF gaps, behind the barrier) the first ones of the next
                 if (ks + PF < KS) fa[ks % PF] = la[(ks + PF) * 64 + lane];
                 else if (more) fa[ks % PF] = ln[(ks + PF - KS) * 64 + lane];
-                x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bf[0][ks], ks == 0 ? zero : x0, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[0][ks], a, ks == 0 ? zero : x0, 0, 0, 0);
                 if (!FIRST) piece(y0, y1, 2 * ks);
                 // the staged tile i + 1 goes to its slot in the first NLD gaps; then the barrier; then the loads of i + 2
                 if (ks < NLD && more) stage_store_one(nxt, ks);
                 __builtin_amdgcn_sched_barrier(0);
-                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bf[1][ks], ks == 0 ? zero : x1, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[1][ks], a, ks == 0 ? zero : x1, 0, 0, 0);
                 if (!FIRST) piece(y0, y1, 2 * ks + 1);
                 if (ks == NLD) __syncthreads();
                 if (ks > NLD && ks <= 2 * NLD && more2) stage_load_one(mt0 + i + 2, ks - NLD - 1);

@@ -23,7 +23,7 @@ import torch
 
 from . import tucker as _tucker
 
-ENABLED = os.environ.get("R_TUCKER_AMD_GRAPH", "1") == "1"
+ENABLED = os.environ.get("R_TUCKER_AMD_GRAPH", "0") == "1"     # opt-in: see IN_FLIGHT below and DESIGN.md section 8
 EAGER_STEPS = 2
 # Replays the host may run ahead of the GPU.  A replay is ~700 kernel nodes and takes the GPU ~25 ms but the host
 # ~2 ms to enqueue: unthrottled, a whole epoch (169 replays, ~120 000 packets) sits in the queue.  Free-running
