@@ -303,6 +303,40 @@ int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t 
 int rtk_rank_metrics_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double *acc5, void *stream);
 
 /*
+ * Training forward with the loss fused into the score kernel's epilogue (reference train.py:79,136:
+ * nn.BCELoss(mean) of sigmoid scores against label-smoothed targets y = (1 - eps) multi_hot + eps / N,
+ * src/data/Dataset.py:51-52).  fp32 operands, c <= 512, packed query planes from rtk_query_vectors_f32.
+ *   rtk_score_packed_bce_f32: x_out[d, j] = p - eps / N  (0 where the fp32 score saturated to 1.0f / 0.0f: the
+ *       reference's autograd gives a zero logit gradient there) = d BCE / d logit of a NEGATIVE entry, up to the
+ *       factor g / (B N); partials_out[0 .. rtk_score_bce_partials()) receive per-workgroup sums of the entries' BCE
+ *       terms taken as negatives (unused slots are zeroed).  The B x N matrix is written once, never re-read.
+ *   rtk_bce_patch_pos_f32: the known objects of every pair (CSR, as rtk_bce_rows_f32): x <- x - (1 - eps), and
+ *       rows_pos_out[d] = the correction of row d's BCE sum.
+ *   loss = (sum(partials) + sum(rows_pos)) / (B N);   d loss / d logits = x * g / (B N).
+ */
+int rtk_score_bce_partials(void);
+int rtk_score_packed_bce_f32(const void *q_packed, int64_t batch, int c, const float *O, int64_t n_local,
+                             float *x_out, int64_t ld_out, float label_smoothing, double *partials_out, void *stream);
+int rtk_bce_patch_pos_f32(float *X, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
+                          const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
+                          double *rows_pos_out, void *stream);
+
+/*
+ * The exchange step of the entity-sharded path (BASELINE.json north_star: "RCCL all-gather of
+ * per-shard scores over xGMI"): one process per GPU, rank p holds entity rows [p * n_loc, (p + 1) * n_loc) and
+ * writes its (B, pitch) score block into slot p of a (world, B, pitch) buffer; rtk_allgather_scores completes the
+ * buffer IN PLACE on every rank (ncclAllGather's in-place form, enqueued on `stream`).  RCCL is bound at run time
+ * (the copy already in the process, else librccl.so of the ROCm install); without it these return
+ * RTK_ERR_UNSUPPORTED.  rtk_comm_unique_id: 128 bytes for rank 0 to hand to its peers by the host's own means.
+ * rtk_comm_init uses the calling thread's current device; one communicator per process and GPU.
+ * No counterpart in the reference (single device): the Python mirror is r_tucker_amd.sharded.
+ */
+int rtk_comm_unique_id(void *id_out_128_bytes);
+int rtk_comm_init(int rank, int world, const void *unique_id_128_bytes, void **comm_out);
+int rtk_allgather_scores(void *comm, void *buf, size_t bytes_per_rank, void *stream);
+int rtk_comm_destroy(void *comm);
+
+/*
  * Batched small Cholesky-QR factor step, float64: for each of `batch` symmetric positive semidefinite k x k Gram
  * matrices S = W^T W (row-major, contiguous, k <= 256), with D = sqrt(diag S) if `equilibrate` (else I) and
  *     A = D^-1 S D^-1 + (shift_diag + shift_trace * trace(S)) I = L L^T,

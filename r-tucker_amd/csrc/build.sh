@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-function"
-SRCS="rtk_abi rtk_gemm_f32 rtk_gemm_sf16 rtk_query rtk_query_bwd rtk_score_split rtk_score_ws rtk_score_bf16 rtk_rank rtk_bce rtk_chol"
+SRCS="rtk_abi rtk_gemm_f32 rtk_gemm_sf16 rtk_query rtk_query_bwd rtk_score_split rtk_score_ws rtk_score_bf16 rtk_rank rtk_bce rtk_chol rtk_comm"
 pids=()
 objs=()
 # incremental: a source is recompiled when it, any header here or the public header is newer than its object
@@ -18,5 +18,5 @@ for f in $SRCS; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librtucker_hip.so" "${objs[@]}"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/librtucker_hip.so" "${objs[@]}" -ldl
 echo "built $OUT/librtucker_hip.so"

@@ -104,6 +104,38 @@ __global__ __launch_bounds__(256) void bce_grad_all_kernel(float *__restrict__ P
     }
 }
 
+// The positives of the fused training forward (rtk_score_packed_bce_f32 wrote x = p - t0, or 0 where p was saturated,
+// and summed every entry's BCE term as a negative): x <- x - dt, and the row's correction of the loss,
+// -dt (ln p - ln(1 - p)) with p = x + t0.  A stored 0 at a positive is a score saturated to 1.0f (a positive that
+// saturates to 0.0f needs a logit below -88): it stays 0 and its correction is -dt (0 - (-100)).  One workgroup per row.
+__global__ __launch_bounds__(64) void bce_patch_pos_kernel(float *__restrict__ X, int N, int64_t ld, float t0, float dt,
+                                                           const int64_t *__restrict__ pair_slot,
+                                                           const int64_t *__restrict__ pair_ptr,
+                                                           const int64_t *__restrict__ pair_obj,
+                                                           double *__restrict__ rows_pos) {
+    const int d = blockIdx.x;
+    float *row = X + (int64_t)d * ld;
+    const int64_t sl = pair_slot[d];
+    float acc = 0.f;
+    for (int64_t i = pair_ptr[sl] + threadIdx.x; i < pair_ptr[sl + 1]; i += 64) {
+        const int64_t j = pair_obj[i];
+        if (j >= 0 && j < N) {
+            const float x = row[j];
+            if (x == 0.0f) {
+                acc += dt * 100.0f;                      // clog(1) - clog(0) = 0 - (-100)
+            } else {
+                const float p = x + t0;
+                acc += dt * (clog(p) - clog(1.0f - p));
+                row[j] = x - dt;
+            }
+        }
+    }
+    double a = (double)acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (threadIdx.x == 0) rows_pos[d] = -a;
+}
+
 int check(const char *fn, const float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
           const int64_t *pair_ptr, const int64_t *pair_obj, float eps) {
     RTK_REQUIRE(P && pair_slot && pair_ptr && pair_obj, RTK_ERR_BAD_ARG, "%s: null operand", fn);
@@ -145,4 +177,17 @@ extern "C" int rtk_bce_grad_f32(float *P, int64_t batch, int64_t n_ent, int64_t 
     if (vec) hipLaunchKernelGGL((bce_grad_all_kernel<true>), grid, dim3(256), 0, st, P, (int)batch, (int)n_ent, ld, t0, grad_loss, scale);
     else hipLaunchKernelGGL((bce_grad_all_kernel<false>), grid, dim3(256), 0, st, P, (int)batch, (int)n_ent, ld, t0, grad_loss, scale);
     return rtk_check_launch("rtk_bce_grad_f32");
+}
+
+extern "C" int rtk_bce_patch_pos_f32(float *X, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
+                                     const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
+                                     double *rows_pos_out, void *stream) {
+    int rc = check("rtk_bce_patch_pos_f32", X, batch, n_ent, ld, pair_slot, pair_ptr, pair_obj, label_smoothing);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(rows_pos_out, RTK_ERR_BAD_ARG, "rtk_bce_patch_pos_f32: null output");
+    RTK_REQUIRE(batch < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_bce_patch_pos_f32: batch too large");
+    const float t0 = label_smoothing / (float)n_ent, dt = 1.0f - label_smoothing;
+    hipLaunchKernelGGL(bce_patch_pos_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, X, (int)n_ent, ld, t0, dt,
+                       pair_slot, pair_ptr, pair_obj, rows_pos_out);
+    return rtk_check_launch("rtk_bce_patch_pos_f32");
 }

@@ -52,6 +52,24 @@ int launch_ks(const unsigned char *qp, int B, const float *O, int N, int c, floa
     return launch_one<KS, 2, MINW>(qp, B, O, N, c, out, ld, o_vec, grid, st);
 }
 
+// training forward: x = p - t0 and the negatives' BCE terms (score_split_kernel<..., LOSS = true>)
+template <int KS, int MINW>
+int launch_loss(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld, bool o_vec, float t0,
+                double *partials, hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)(RTK_PACK_HDR + 2 * KS * 1024);
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (smem > 64 * 1024) {
+        const int rc = rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&score_split_kernel<KS, 2, MINW, 0, true>), (int)smem,
+                                              lds_ok, "score_split_kernel (loss)");
+        if (rc != RTK_OK) return rc;
+    }
+    const int64_t units = rtk_cdiv(N, 128) * rtk_cdiv(B, 32);
+    const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
+    hipLaunchKernelGGL((score_split_kernel<KS, 2, MINW, 0, true>), dim3(grid), dim3(256), smem, st, qp, B, O, N, c, out, ld,
+                       o_vec, t0, partials);
+    return RTK_OK;
+}
+
 }  // namespace
 
 int rtk_score_ws_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
@@ -115,4 +133,43 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
 #undef RTK_KS
     if (rc != RTK_OK) return rc;
     return rtk_check_launch("rtk_score_packed_f32");
+}
+
+extern "C" int rtk_score_bce_partials(void) { return 512; }      // >= the largest grid of the loss kernel
+
+extern "C" int rtk_score_packed_bce_f32(const void *q_packed, int64_t batch, int c, const float *O, int64_t n_local,
+                                        float *x_out, int64_t ld_out, float label_smoothing, double *partials_out,
+                                        void *stream) {
+    RTK_REQUIRE(q_packed && O && x_out && partials_out, RTK_ERR_BAD_ARG, "rtk_score_packed_bce_f32: null operand");
+    RTK_REQUIRE(batch > 0 && n_local > 0 && c > 0, RTK_ERR_BAD_ARG, "rtk_score_packed_bce_f32: sizes must be positive");
+    RTK_REQUIRE(ld_out >= n_local, RTK_ERR_BAD_ARG, "rtk_score_packed_bce_f32: ld_out < n_local");
+    RTK_REQUIRE(ld_out < (1ll << 24), RTK_ERR_UNSUPPORTED, "rtk_score_packed_bce_f32: ld_out >= 2^24");
+    RTK_REQUIRE(batch < (1ll << 31) && n_local < (1ll << 31) - 256, RTK_ERR_UNSUPPORTED, "rtk_score_packed_bce_f32: dimension too large");
+    RTK_REQUIRE(rtk_split_ksteps_supported(c), RTK_ERR_UNSUPPORTED, "rtk_score_packed_bce_f32: c=%d > 512 not supported", c);
+    RTK_REQUIRE(label_smoothing >= 0.f && label_smoothing < 1.f, RTK_ERR_BAD_ARG, "rtk_score_packed_bce_f32: label smoothing %g outside [0, 1)", (double)label_smoothing);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(partials_out, 0, 512 * sizeof(double), st) != hipSuccess) {
+        rtk_set_error("rtk_score_packed_bce_f32: clearing the partial sums failed");
+        return RTK_ERR_LAUNCH;
+    }
+    const int ks = (c + 15) / 16;
+    const bool o_vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
+    const int B = (int)batch, N = (int)n_local;
+    const float t0 = label_smoothing / (float)n_local;
+    const unsigned char *qp = (const unsigned char *)q_packed;
+    int rc = RTK_OK;
+#define RTK_KS(K_, W_) \
+    case K_: rc = launch_loss<K_, W_>(qp, B, O, N, c, x_out, ld_out, o_vec, t0, partials_out, st); break;
+    switch (ks) {
+        RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
+        RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)
+        RTK_KS(17, 1) RTK_KS(18, 1) RTK_KS(19, 1) RTK_KS(20, 1) RTK_KS(21, 1) RTK_KS(22, 1) RTK_KS(23, 1) RTK_KS(24, 1)
+        RTK_KS(25, 1) RTK_KS(26, 1) RTK_KS(27, 1) RTK_KS(28, 1) RTK_KS(29, 1) RTK_KS(30, 1) RTK_KS(31, 1) RTK_KS(32, 1)
+        default:
+            rtk_set_error("rtk_score_packed_bce_f32: unsupported k-step count %d", ks);
+            return RTK_ERR_UNSUPPORTED;
+    }
+#undef RTK_KS
+    if (rc != RTK_OK) return rc;
+    return rtk_check_launch("rtk_score_packed_bce_f32");
 }

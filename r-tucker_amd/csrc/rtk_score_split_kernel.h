@@ -12,10 +12,19 @@ __device__ unsigned long long g_istamps[4096 * 8];   // ABL bit 7: s_memtime sta
 
 // SIGMOID: 0 = raw logits, 1 = ocml expf + IEEE divide (torch-CPU formula, ~25 VALU),
 //          2 = 1 / (1 + 2^(-z log2 e)) on v_exp_f32 + v_rcp_f32 (4 VALU, 1 ulp each)
-template <int KS, int SIGMOID, int MINW, unsigned ABL = 0>
+// LOSS (training forward; reference train.py:79,136 + Dataset.py:51-52): instead of the probability p
+// the epilogue writes x = p - t0 (0 where p is saturated to exactly 1.0f or 0.0f: the reference's autograd returns
+// a zero logit gradient there) -- d BCE / d logit of an entry whose label-smoothed target is the negatives'
+// t0 = eps / N, up to the factor g / (B N) that the backward applies to the small operands -- and adds the entry's
+// BCE term -(t0 ln p + (1 - t0) ln(1 - p)) (logs on v_log_f32, clamped at -100 like torch) to a per-lane sum that
+// leaves the kernel as ONE double per workgroup in partials[blockIdx.x].  The few positives are patched afterwards
+// (rtk_bce.hip: bce_patch_pos_kernel).  The B x N matrix is written once and never re-read in the forward.
+__device__ __forceinline__ float split_clog(float x) { return fmaxf(__builtin_amdgcn_logf(x) * 0.6931471805599453f, -100.0f); }
+
+template <int KS, int SIGMOID, int MINW, unsigned ABL = 0, bool LOSS = false>
 __global__ __launch_bounds__(256, MINW) void score_split_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
-    float *__restrict__ out, int64_t ld_out, bool o_vec) {
+    float *__restrict__ out, int64_t ld_out, bool o_vec, float t0 = 0.f, double *__restrict__ partials = nullptr) {
     // ABL != 0 only in tools/ablate (compile-time ablations): bit0 skip staging, bit1 skip MFMA,
     // bit2 skip stores, bit3 skip the query sweep (prologue only), bit4 skip the O conversion,
     // bit5 skip the barriers
@@ -35,6 +44,9 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
     const int64_t lin_end = U * (blockIdx.x + 1) / gridDim.x;
 
     int stamp_n = 0;
+    double loss_sum = 0.0;         // LOSS: this lane's share of the batch's BCE terms (as +sum of y ln p + (1-y) ln(1-p))
+    float loss_tile = 0.f;
+    int ep_rows = 0;
     if (off(64) && t == 0) g_stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     while (lin < lin_end) {
         const int ntile = (int)(lin / n_mt), mt0 = (int)(lin % n_mt);
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
         const unsigned ld4 = (unsigned)(ld_out * 4);
         auto epilogue_begin = [&](int mt, bool live) {
             const int rows = live ? min(32, B - mt * 32) : 0;
+            ep_rows = rows;
             ers = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)max(mt, 0) * 32 * ld_out, 0,
                                                     (unsigned)(rows * ld_out * 4), 0x00020000);
             ep_off = voff;
@@ -153,6 +166,11 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 if (SIGMOID == 2) pv = __builtin_amdgcn_rcpf(1.0f + ep_d);   // v_exp_f32 / v_rcp_f32 are 1-ulp
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
                 const int row = (e & 3) + 8 * (e >> 2);  // + 4*h inside voff
+                if (LOSS) {
+                    const float term = t0 * split_clog(pv) + (1.0f - t0) * split_clog(1.0f - pv);
+                    if (j < N && row + 4 * h < ep_rows) loss_tile += term;
+                    pv = (pv == 1.0f || pv == 0.0f) ? 0.0f : pv - t0;
+                }
                 if (off(4)) {
                     if (pv == 12345.678f) out[0] = pv;
                 } else {
@@ -217,6 +235,10 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) prev[4 * g + q] = acc[4 * g + q] * sv[q] * us_o;
             }
+            if (LOSS) {
+                loss_sum += (double)loss_tile;
+                loss_tile = 0.f;
+            }
             stage_store(cur ^ 1);  // unconditional: a stale tile in the spare buffer is never read
             if (stamp_it) g_istamps[(blockIdx.x * 4 + wave) * 8 + 3] = __builtin_amdgcn_s_memtime();
             if (!off(32)) __syncthreads();
@@ -225,6 +247,19 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
         epilogue_begin(mt0 + cnt - 1, true);
 #pragma unroll
         for (int pc = 0; pc < 32; ++pc) piece(prev, pc);
+        if (LOSS) {
+            loss_sum += (double)loss_tile;
+            loss_tile = 0.f;
+        }
+    }
+    if (LOSS) {     // one double per workgroup, lanes and waves added in a fixed order (deterministic)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) loss_sum += __shfl_xor(loss_sum, o);
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(lds);
+        if (lane == 0) red[wave] = loss_sum;
+        __syncthreads();
+        if (t == 0) partials[blockIdx.x] = -(red[0] + red[1] + red[2] + red[3]);
     }
     if (off(64) && t == 0) g_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }

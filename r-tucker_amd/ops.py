@@ -35,6 +35,9 @@ ROW_ALIGN = max(1, int(os.environ.get("R_TUCKER_AMD_ROW_ALIGN", "32")))
 # The two B x N sized backward products (dO = dZ^T v, dv = dZ O): "split_fp16" = three f16 MFMAs per k-step on
 # hi/lo halves like the forward (normwise fp32-class accuracy), "f32" = the exact fp32 MFMA GEMM (5x slower).
 BACKWARD_GEMM = os.environ.get("R_TUCKER_AMD_BWD_GEMM", "split_fp16")
+# Training loss: "1" = BCE terms and the logit gradient's base written by the score kernel's epilogue (the B x N matrix
+# is written once in the forward and read only by the backward GEMMs); "0" = scores, then two more passes over them.
+FUSED_BCE = os.environ.get("R_TUCKER_AMD_FUSED_BCE", "1") == "1"
 
 
 def alloc_scores(B, N, device, lead=(), dtype=torch.float32):
@@ -320,14 +323,16 @@ def _splits_for(M, N, K):
     return int(max(1, min(64, 512 // max(tiles, 1), K // 512)))
 
 
-def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt, dz_bound=None):
+def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt, dz_bound=None, scale=None):
     """(g_core, g_R, g_S, g_O) from dZ = d loss / d logits (B, N) fp32 and the saved fp32 query vectors,
     all in HIP kernels with a fixed summation order (bit-identical from run to run): dO = dZ^T v and
     dv = dZ O (split-K slabs added in chunk order) on the split-fp16 MFMA path of the forward
     (``BACKWARD_GEMM = "f32"`` / ``R_TUCKER_AMD_BWD_GEMM=f32``: the exact fp32 MFMA GEMM), then the stage-1
     backward ``rtk_query_vectors_bwd_f32`` (two more GEMMs and a deterministic row scatter).  ``dz_bound``: a
     one-element device tensor >= max|dZ| when the caller knows one (the BCE gradient does); otherwise one
-    max-reduction over dZ finds it."""
+    max-reduction over dZ finds it.  ``scale``: a one-element device tensor s -- the gradients of ``s * dZ`` are
+    returned without a pass over dZ: everything is linear in dZ, so s multiplies the small operands
+    (``v`` for dO, ``dv`` before the stage-1 backward)."""
     lib = _lib.load()
     dev = dZ.device
     B, N = dZ.shape
@@ -348,16 +353,18 @@ def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt, dz_bound=None):
             if dz_bound is None:
                 dz_bound = absmax(dZ, ldz, 0)
             dz_bound = dz_bound.to(device=dev, dtype=torch.float32).reshape(1).contiguous()
-            v_bound = absmax(v, c, 1)
+        v_o = v if scale is None else v * scale.to(device=dev, dtype=torch.float32).reshape(1)      # (B, c): dO's small operand
+        if sf16:
+            v_bound = absmax(v_o, c, 1)
         if needs[3]:
             # gO[j, k] = sum_d dZ[d, j] * v[d, k]   -- fp32 MFMA GEMM, both operands M-major
             gO = torch.empty((N, c), dtype=torch.float32, device=dev)
             if sf16:
-                _lib.check(lib.rtk_gemm_sf16_splitk(dZ.data_ptr(), 0, ldz, dz_bound.data_ptr(), v.data_ptr(), 0, c,
+                _lib.check(lib.rtk_gemm_sf16_splitk(dZ.data_ptr(), 0, ldz, dz_bound.data_ptr(), v_o.data_ptr(), 0, c,
                                                     v_bound.data_ptr(), gO.data_ptr(), c, N, c, B, 1, None, 0, sp),
                            "rtk_gemm_sf16_splitk (dO)")
             else:
-                _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, ldz, v.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
+                _lib.check(lib.rtk_gemm_f32(dZ.data_ptr(), 0, ldz, v_o.data_ptr(), 0, c, gO.data_ptr(), c, N, c, B, 0, sp),
                            "rtk_gemm_f32 (dO)")
         if needs[0] or needs[1] or needs[2]:
             # dv[d, k] = sum_j dZ[d, j] * O[j, k]   -- K = N entities: split-K, slabs reduced in chunk order
@@ -372,6 +379,8 @@ def _grads_from_dZ(core, R, S, O, h, r, v, dZ, needs, pdt, dz_bound=None):
             else:
                 _lib.check(lib.rtk_gemm_f32_splitk(dZ.data_ptr(), 1, ldz, Of.data_ptr(), 0, c, dv.data_ptr(), c, B, c, N,
                                                    splits, skw.data_ptr(), skw.numel(), sp), "rtk_gemm_f32_splitk (dv)")
+            if scale is not None:
+                dv = dv * scale.to(device=dev, dtype=torch.float32).reshape(1)
             gcore = torch.empty_like(core) if needs[0] else None
             gR = torch.empty_like(R) if needs[1] else None
             gS = torch.empty_like(S) if needs[2] else None
@@ -434,6 +443,11 @@ class _BceLoss1vN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, core, R, S, O, subject_idx, relation_idx, pair_slot, pair_ptr, pair_obj, label_smoothing):
+        ctx.fused = False
+        if (FUSED_BCE and core.dtype == torch.float32 and core.is_cuda and core.shape[2] <= 512 and core.shape[1] == core.shape[2]
+                and subject_idx.numel() > 0):
+            return _BceLoss1vN._forward_fused(ctx, core, R, S, O, subject_idx, relation_idx, pair_slot, pair_ptr, pair_obj,
+                                              float(label_smoothing))
         # the scores never leave this function pair: aligned rows for them too
         P, v = _forward(core, R, S, O, subject_idx, relation_idx, True, False, want_v=True, padded=True)
         lib = _lib.load()
@@ -450,8 +464,40 @@ class _BceLoss1vN(torch.autograd.Function):
         return (rows.sum() / (B * N)).to(torch.float32)
 
     @staticmethod
+    def _forward_fused(ctx, core, R, S, O, subject_idx, relation_idx, pair_slot, pair_ptr, pair_obj, eps):
+        """Loss fused into the score kernel's epilogue (``rtk_score_packed_bce_f32``): the B x N matrix is written once,
+        as ``x = p - eps / N`` (the logit gradient of a negative, up to g / (B N)), never re-read in the forward; the few
+        positives are patched by ``rtk_bce_patch_pos_f32``."""
+        lib = _lib.load()
+        dev = core.device
+        core, R, S, O = _f32c("core", core), _f32c("R", R), _f32c("S", S), _f32c("O", O)
+        h, r = _idx("subject_idx", subject_idx, dev), _idx("relation_idx", relation_idx, dev)
+        B, N, c = h.numel(), O.shape[0], core.shape[2]
+        v, qp = query_vectors(core.detach(), R.detach(), S.detach(), h, r, packed=True)
+        X = alloc_scores(B, N, dev)
+        partials = torch.empty(lib.rtk_score_bce_partials(), dtype=torch.float64, device=dev)
+        rows_pos = torch.empty(B, dtype=torch.float64, device=dev)
+        ld = X.stride(0) if B > 1 else N
+        with torch.cuda.device(dev):
+            sp = _stream_ptr(dev)
+            _lib.check(lib.rtk_score_packed_bce_f32(qp.data_ptr(), B, c, O.data_ptr(), N, X.data_ptr(), ld, eps,
+                                                    partials.data_ptr(), sp), "rtk_score_packed_bce_f32")
+            _lib.check(lib.rtk_bce_patch_pos_f32(X.data_ptr(), B, N, ld, pair_slot.data_ptr(), pair_ptr.data_ptr(),
+                                                 pair_obj.data_ptr(), eps, rows_pos.data_ptr(), sp), "rtk_bce_patch_pos_f32")
+        ctx.save_for_backward(core, R, S, O, h, r, v, X, pair_slot, pair_ptr, pair_obj)
+        ctx.eps = eps
+        ctx.fused = True
+        return ((partials.sum() + rows_pos.sum()) / (B * N)).to(torch.float32)
+
+    @staticmethod
     def backward(ctx, grad_loss):
         core, R, S, O, h, r, v, P, pair_slot, pair_ptr, pair_obj = ctx.saved_tensors
+        if ctx.fused:
+            B, N = P.shape
+            g = grad_loss.to(device=P.device, dtype=torch.float32).reshape(1) * (1.0 / (B * N))
+            # X = (p - y) unscaled, |X| <= 1: the GEMMs' operand bound; g / (B N) rides on the small operands
+            return _grads_from_dZ(core, R, S, O, h, r, v, P, ctx.needs_input_grad, core.dtype,
+                                  dz_bound=torch.ones(1, dtype=torch.float32, device=P.device), scale=g) + (None,) * 6
         if getattr(ctx, "spent", False):
             raise RuntimeError("bce_loss_1vN: backward called twice (the saved scores are overwritten by the first pass)")
         ctx.spent = True

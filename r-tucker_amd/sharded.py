@@ -61,7 +61,7 @@ class ShardedEntityScorer:
     """
 
     def __init__(self, n_ent: int, group=None, local_score=None, stage1="auto", score_dtype=torch.float32,
-                 query_vectors_fn=None, score_from_v_fn=None):
+                 query_vectors_fn=None, score_from_v_fn=None, collective="torch"):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -78,6 +78,56 @@ class ShardedEntityScorer:
         self.score_from_v_fn = score_from_v_fn
         self._gathered = None
         self._v_all = None
+        # the score exchange: "torch" = torch.distributed's all_gather_into_tensor on the process group (RCCL when
+        # the backend is "nccl"); "abi" = the C ABI's own communicator (rtk_comm_init / rtk_allgather_scores:
+        # RCCL bound by the library itself -- the path a non-Python host takes; torch.distributed only carries the
+        # 128-byte unique id from rank 0 to the others, once)
+        if collective not in ("torch", "abi"):
+            raise ValueError("collective must be torch | abi")
+        self.collective = collective
+        self._comm = None
+
+    def _abi_comm(self, device):
+        if self._comm is None:
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = (C.c_ubyte * 128)()
+                _lib.check(lib.rtk_comm_unique_id(buf), "rtk_comm_unique_id")
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            if self.world > 1:
+                backend = dist.get_backend(self.group)
+                carrier = ident.to(device) if backend == "nccl" else ident
+                dist.broadcast(carrier, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                ident = carrier.cpu()
+            raw = bytes(ident.tolist())
+            comm = C.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.rtk_comm_init(self.rank, self.world, raw, C.byref(comm)), "rtk_comm_init")
+            self._comm = comm
+        return self._comm
+
+    def close(self):
+        """Destroy the C-ABI communicator, if one was made."""
+        if self._comm is not None:
+            from . import _lib
+            _lib.check(_lib.load().rtk_comm_destroy(self._comm), "rtk_comm_destroy")
+            self._comm = None
+
+    def _exchange(self, g: torch.Tensor):
+        """Complete the (P, B, pitch) buffer in place: slot p comes from rank p."""
+        if self.collective == "abi":
+            from . import _lib
+            with torch.cuda.device(g.device):
+                _lib.check(_lib.load().rtk_allgather_scores(self._abi_comm(g.device), g.data_ptr(),
+                                                            g[0].numel() * g.element_size(),
+                                                            torch.cuda.current_stream(g.device).cuda_stream),
+                           "rtk_allgather_scores")
+        elif self.world > 1:
+            # in-place all-gather of the padded storage: input is the rank-th slice of the output buffer
+            dist.all_gather_into_tensor(g.view(-1), g[self.rank].view(-1), group=self.group)
 
     def local_block(self, full_entity_matrix: torch.Tensor) -> torch.Tensor:
         return self.shards.take(full_entity_matrix, self.rank)
@@ -140,9 +190,7 @@ class ShardedEntityScorer:
         n_loc = self.shards.n_loc
         mine = g[self.rank][:, :n_loc]                        # (B, n_loc) view: the kernel writes in place
         self._score_local(core, R, S, O_loc, subject_idx, relation_idx, mine, tables=tables, **kw)
-        if self.world > 1:
-            # in-place all-gather of the padded storage: input is the rank-th slice of the output buffer
-            dist.all_gather_into_tensor(g.view(-1), g[self.rank].view(-1), group=self.group)
+        self._exchange(g)
         return g[:, :, :n_loc]
 
     def view_BPn(self, gathered: torch.Tensor) -> torch.Tensor:

@@ -80,3 +80,17 @@ def test_model_surface_on_cpu():
     s.init()
     assert list(s.state_dict().keys()) == ["core", "E.weight", "R.weight"]
     assert callable(m(torch.tensor([1]), torch.tensor([2])))
+
+
+def test_collective_entry_points_validate_without_a_gpu(lib):
+    """rtk_comm_* / rtk_allgather_scores: argument errors are status codes, nothing touches a device."""
+    comm = C.c_void_p()
+    assert lib.rtk_comm_init(0, 0, b"\0" * 128, C.byref(comm)) == -1 and b"world" in lib.rtk_last_error_string()
+    assert lib.rtk_comm_init(2, 2, b"\0" * 128, C.byref(comm)) == -1 and comm.value is None
+    assert lib.rtk_comm_init(0, 1, None, C.byref(comm)) == -1 and b"unique_id" in lib.rtk_last_error_string()
+    assert lib.rtk_comm_init(0, 1, b"\0" * 128, None) == -1
+    assert lib.rtk_comm_unique_id(None) == -1
+    assert lib.rtk_allgather_scores(None, 1, 16, None) == -1 and b"communicator" in lib.rtk_last_error_string()
+    assert lib.rtk_comm_destroy(None) == 0
+    assert lib.rtk_gram_factor_f64(None, 1, 4, 1, 0.0, 0.0, 1, 2, None) == -1
+    assert lib.rtk_gram_factor_f64(1, 1, 300, 1, 0.0, 0.0, 2, 3, None) == -3 and b"k=300" in lib.rtk_last_error_string()

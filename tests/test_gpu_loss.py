@@ -38,9 +38,14 @@ class _Pairs:
         return (1 - self.label_smoothing) * t + self.label_smoothing / self.n_ent
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("mode", ["asym", "sym"])
 @pytest.mark.parametrize("eps", [0.0, 0.1])
-def test_loss_and_gradients_against_oracle(rt, mode, eps):
+def test_loss_and_gradients_against_oracle(rt, mode, eps, fused, monkeypatch):
+    """fused: BCE terms + the logit gradient's base from the score kernel's epilogue (rtk_score_packed_bce_f32 +
+    rtk_bce_patch_pos_f32); not fused: scores, then rtk_bce_rows_f32 / rtk_bce_grad_f32 over them."""
+    from r_tucker_amd import ops
+    monkeypatch.setattr(ops, "FUSED_BCE", fused)
     n_ent, n_rel, B, rank = 3001, 7, 48, (5, 32, 32)      # odd N: scalar path of the in-place gradient
     core, R, S, O = gen.make_params(n_ent, n_rel, rank, 41, shared=(mode == "sym"))
     rng = np.random.default_rng(41)
@@ -84,3 +89,36 @@ def test_wn18rr_train_batch_loss(rt):
         loss = rt.bce_loss_1vN(*[torch.from_numpy(x).cuda() for x in (core, R, S, O)], h.cuda(), r.cuda(), flt,
                                torch.from_numpy(ids).cuda(), label_smoothing=0.1)
     assert abs(loss.item() - ref) <= 2e-6 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("scale", [1.0, 40.0])
+def test_fused_loss_equals_the_three_pass_form(rt, scale, monkeypatch):
+    """Same batch through both forms, ragged sizes (B = 70: last query tile of 6 rows; N = 3003), and with logits
+    scaled until scores saturate to exactly 1.0f / 0.0f (zero logit gradient there, BCE log clamped at -100): the
+    loss agrees to rounding, every gradient to the accuracy of the backward GEMMs."""
+    from r_tucker_amd import ops
+    n_ent, n_rel, B, rank = 3003, 7, 70, (4, 48, 48)
+    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 43)
+    core = core * scale
+    rng = np.random.default_rng(43)
+    pairs = [(int(s), int(r)) for s, r in zip(rng.permutation(n_ent)[:120], rng.integers(0, n_rel, 120))]
+    lists = [rng.integers(0, n_ent, rng.integers(1, 12)).tolist() for _ in pairs]
+    ds = _Pairs(pairs, lists, n_ent, 0.1)
+    ids = rng.permutation(120)[:B]
+    h = torch.from_numpy(ds.features[ids, 0].copy()).cuda()
+    r = torch.from_numpy(ds.features[ids, 1].copy()).cuda()
+    flt = rt.DeviceFilter(ds, "cuda")
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_BCE", fused)
+        ps = [torch.from_numpy(x).cuda().requires_grad_(True) for x in (core, R, S, O)]
+        loss = rt.bce_loss_1vN(*ps, h, r, flt, torch.from_numpy(ids).cuda(), label_smoothing=0.1)
+        (loss * 0.5).backward()
+        out[fused] = (loss.item(), [p.grad.clone() for p in ps])
+    if scale > 1:
+        with torch.no_grad():
+            P = rt.score_1vN(*[torch.from_numpy(x).cuda() for x in (core, R, S, O)], h, r)
+        assert int((P == 1.0).sum()) > 0 and int((P == 0.0).sum()) >= 0        # the saturated branch is exercised
+    assert abs(out[True][0] - out[False][0]) <= 2e-6 * max(1.0, abs(out[False][0]))
+    for a, b in zip(out[True][1], out[False][1]):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-12

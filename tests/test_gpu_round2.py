@@ -455,3 +455,33 @@ def test_container_norm_in_the_reference_loss_fn(rt):
     Ts = rt.SFTucker(leaves[0].detach(), [leaves[1].detach()], num_shared_factors=2, shared_factor=leaves[2].detach())
     dense_s = np.einsum("abc,ia,jb,kc->ijk", core.astype(np.float64), R.astype(np.float64), S.astype(np.float64), S.astype(np.float64))
     assert abs(Ts.norm().item() - np.linalg.norm(dense_s)) <= 1e-4 * np.linalg.norm(dense_s)
+
+
+def test_abi_collective_one_rank_roundtrip():
+    """rtk_comm_unique_id / rtk_comm_init / rtk_allgather_scores / rtk_comm_destroy through ctypes on one GPU (a
+    one-rank RCCL communicator: the in-place all-gather leaves the buffer as it is), and the sharded scorer driven
+    through it gives the single-device scores."""
+    import ctypes as C
+    import r_tucker_amd as rt
+    from r_tucker_amd import _lib, synthetic as gen
+    lib = _lib.load()
+    ident = (C.c_ubyte * 128)()
+    _lib.check(lib.rtk_comm_unique_id(ident), "rtk_comm_unique_id")
+    assert any(ident)
+    comm = C.c_void_p()
+    _lib.check(lib.rtk_comm_init(0, 1, ident, C.byref(comm)), "rtk_comm_init")
+    buf = torch.arange(4096, dtype=torch.float32, device="cuda")
+    want = buf.clone()
+    _lib.check(lib.rtk_allgather_scores(comm, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream),
+               "rtk_allgather_scores")
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    _lib.check(lib.rtk_comm_destroy(comm), "rtk_comm_destroy")
+
+    n_ent, n_rel, B, rank = 3000, 11, 40, (4, 32, 32)
+    core, R, S, O = [torch.from_numpy(x).cuda() for x in gen.make_params(n_ent, n_rel, rank, 5)]
+    h, r = [torch.from_numpy(x).cuda() for x in gen.make_queries(n_ent, n_rel, B, 5)]
+    sc = rt.ShardedEntityScorer(n_ent, collective="abi")
+    P = sc.score(core, R, S, sc.local_block(O), h, r)
+    sc.close()
+    assert torch.equal(P, rt.score_1vN(core, R, S, O, h, r))

@@ -37,6 +37,28 @@ def build_scheduler(opt, cfg):
     raise ValueError(f"unknown scheduler {tc.scheduler!r}")
 
 
+def _coerce(target, name, raw, item):
+    """Value of ``--set SECTION.FIELD=RAW`` by the dataclass field's ANNOTATED type (a float field whose default is
+    the int literal 2000 still takes 0.5 or 1e-2); JSON for tuples / bools / None, the raw string as a last resort."""
+    import dataclasses
+    import typing
+    hints = typing.get_type_hints(type(target)) if dataclasses.is_dataclass(target) else {}
+    want = hints.get(name)
+    try:
+        if want is float:
+            return float(raw)
+        if want is int:
+            return int(raw)
+        if want is str:
+            return raw
+        val = json.loads(raw)
+        return tuple(val) if isinstance(val, list) else val
+    except (ValueError, TypeError):
+        if want in (float, int):
+            raise SystemExit(f"--set {item}: {name} expects a {want.__name__}, got {raw!r}")
+        return raw
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--mode", type=str, help="Model type", required=True)
@@ -81,9 +103,12 @@ def main(argv=None):
     for item in args.overrides:
         key, _, raw = item.partition("=")
         section, _, name = key.partition(".")
-        target = getattr(cfg, section)
-        old = getattr(target, name)
-        setattr(target, name, type(old)(raw) if not isinstance(old, (tuple, bool)) else json.loads(raw))
+        try:
+            target = getattr(cfg, section)
+            getattr(target, name)
+        except AttributeError:
+            raise SystemExit(f"--set {item}: no field {section}.{name} in the configuration")
+        setattr(target, name, _coerce(target, name, raw, item))
     tc = cfg.train_cfg
     if args.checkpoint_path is not None:
         tc.checkpoint_path = args.checkpoint_path
