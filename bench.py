@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--stage1", choices=["auto", "replicated", "split"], default="auto",
                     help="multi-GPU: query vectors computed by every rank, or batch-split + all-gather (auto: split for relation rank > 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prewarm-ms", type=float, default=250.0,
+    ap.add_argument("--prewarm-ms", type=float, default=1000.0,
                     help="untimed clock ramp before the --warmup steps: the same steps for this long (a 20-step run is "
                          "over before the GPU leaves its idle clocks); reported as config.prewarm_ms")
     ap.add_argument("--no-overlap", action="store_true",
@@ -340,8 +340,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     # HIP events bracket the score kernel on its stream on every 8th timed step (an event pair
-    # costs a few us of stream time; sampling keeps the timed region representative)
-    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) if i % 8 == 0 else None
+    # costs a few us of stream time; sampling keeps the timed region representative); short runs
+    # (the driver's 20 steps) sample every 2nd step so that the average rests on ten brackets, not three
+    every = 8 if args.steps >= 200 else 2
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) if i % every == 0 else None
               for i in range(args.steps)]
     barrier()
     t0 = time.perf_counter()

@@ -76,10 +76,6 @@ typedef enum rtk_dtype {
                                   /* `out` holds bf16 scores (what the reference's bf16 model */
                                   /* returns), ld_out counts bf16 elements; pass the pointer  */
                                   /* through the float* parameter                              */
-#define RTK_SCORE_DEEP_K 16u      /* bf16, 256 < c <= 512, c's k-step count a multiple of 4:   */
-                                  /* take the deep-K kernel (one wave per SIMD, 64 entity rows */
-                                  /* per wave) whatever the problem size -- by default it is   */
-                                  /* chosen once the problem fills the chip that way           */
 
 int rtk_version(void);
 const char *rtk_last_error_string(void);

@@ -20,7 +20,6 @@ RTK_SCORE_SIGMOID = 1
 RTK_SCORE_EXACT_F32 = 2
 RTK_SCORE_SIGMOID_FAST = 4
 RTK_SCORE_OUT_BF16 = 8
-RTK_SCORE_DEEP_K = 16
 
 _p, _i, _i64, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_uint
 

@@ -51,6 +51,8 @@ static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, i
     const bool big_a = dtype == RTK_BF16 && a > 32 && a <= 512;   // tables through the bf16 MFMA kernel
     w.core_t = big_a ? take((size_t)a * b * c * 2) : nullptr;
     w.r_packed = big_a ? take(packed_bytes(RTK_BF16, n_u_max, a)) : nullptr;
+    // fp32, a > 32: tables through the split-fp16 GEMM -- operand bounds (256-byte header) + the gathered relation rows
+    if (dtype == RTK_F32 && a > 32) w.r_packed = take(256 + (size_t)n_u_max * a * 4);
     w.grp_cnt = (int32_t *)take((size_t)n_u_max * 8);
     w.grp_order = (int32_t *)take((size_t)batch * 4);
     w.grp_work = (int32_t *)take((size_t)(batch / 4 + n_u_max + 1) * 16);
@@ -61,7 +63,7 @@ static RtkWorkspace carve(void *base, int dtype, int64_t batch, int64_t n_rel, i
 
 // ---- cached relation tables (rtk_relation_tables_* / rtk_query_vectors_from_tables_*) ----------
 int rtk_relation_tables_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel, float *tables,
-                                 hipStream_t st);
+                                 void *r_scratch, hipStream_t st);
 int rtk_relation_tables_bf16_impl(const void *core, int a, int b, int c, const void *R, int64_t n_rel, float *tables,
                                   void *core_t, void *r_packed, hipStream_t st);
 int rtk_from_tables_f32_impl(const float *tables, int64_t n_rel, int b, int c, const float *S, int64_t n_sub,
@@ -89,6 +91,7 @@ static TablesWs carve_tables(void *base, int dtype, int64_t n_rel, int a, int b,
     const bool big_a = dtype == RTK_BF16 && a > 32 && a <= 512;
     w.core_t = big_a ? take((size_t)a * b * c * 2) : nullptr;
     w.r_packed = big_a ? take(packed_bytes(RTK_BF16, n_rel, a)) : nullptr;
+    if (dtype == RTK_F32 && a > 32) w.r_packed = take(256 + (size_t)n_rel * a * 4);   // (as in carve())
     w.total = off;
     return w;
 }
@@ -144,7 +147,8 @@ extern "C" int rtk_relation_tables_f32(const float *core, int a, int b, int c, c
                                        float *tables, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = check_tables("rtk_relation_tables_f32", core, a, b, c, R, n_rel, tables, workspace, workspace_bytes, RTK_F32);
     if (rc != RTK_OK) return rc;
-    return rtk_relation_tables_f32_impl(core, a, b, c, R, n_rel, tables, (hipStream_t)stream);
+    const TablesWs ws = carve_tables(workspace, RTK_F32, n_rel, a, b, c);
+    return rtk_relation_tables_f32_impl(core, a, b, c, R, n_rel, tables, ws.r_packed, (hipStream_t)stream);
 }
 
 extern "C" int rtk_relation_tables_bf16(const void *core, int a, int b, int c, const void *R, int64_t n_rel,

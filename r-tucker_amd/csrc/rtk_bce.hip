@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void bce_grad_all_kernel(float *__restrict__ P
 
 // The positives of the fused training forward (rtk_score_packed_bce_f32 wrote x = p - t0, or 0 where p was saturated,
 // and summed every entry's BCE term as a negative): x <- x - dt, and the row's correction of the loss,
-// -dt (ln p - ln(1 - p)) with p = x + t0.  A stored 0 at a positive is a score saturated to 1.0f (a positive that
-// saturates to 0.0f needs a logit below -88): it stays 0 and its correction is -dt (0 - (-100)).  One workgroup per row.
+// -dt (ln p - ln(1 - p)) with p = x + t0.  A stored zero is a saturated score (+0: 1.0f, -0: 0.0f): it stays zero and its correction
+// uses torch's clamp, ln 0 = -100.  One workgroup per row.
 __global__ __launch_bounds__(64) void bce_patch_pos_kernel(float *__restrict__ X, int N, int64_t ld, float t0, float dt,
                                                            const int64_t *__restrict__ pair_slot,
                                                            const int64_t *__restrict__ pair_ptr,
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(64) void bce_patch_pos_kernel(float *__restrict__ X
         const int64_t j = pair_obj[i];
         if (j >= 0 && j < N) {
             const float x = row[j];
-            if (x == 0.0f) {
-                acc += dt * 100.0f;                      // clog(1) - clog(0) = 0 - (-100)
+            if (x == 0.0f) {                             // saturated: +0 = score 1.0f, -0 = score 0.0f
+                acc += (__builtin_bit_cast(unsigned, x) >> 31) ? -dt * 100.0f : dt * 100.0f;   // clog(p) - clog(1 - p) = -+100
             } else {
                 const float p = x + t0;
                 acc += dt * (clog(p) - clog(1.0f - p));

@@ -686,6 +686,15 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
     }
 }
 
+// rows of R in table-slot order (slots past the batch's distinct relations hold an arbitrary valid row: never read)
+__global__ __launch_bounds__(64) void gather_rel_rows_kernel(const float *__restrict__ R, int a, int n_rel,
+                                                             const int32_t *__restrict__ rel_list, float *__restrict__ out) {
+    const int u = blockIdx.x;
+    int rel = rel_list[u];
+    rel = rel < 0 ? 0 : (rel >= n_rel ? n_rel - 1 : rel);
+    for (int k = threadIdx.x; k < a; k += 64) out[(int64_t)u * a + k] = R[(int64_t)rel * a + k];
+}
+
 }  // namespace
 
 int rtk_gemm_f32_ex(const void *A, int a_kmajor, int64_t lda, const int32_t *a_rows, const void *B,
@@ -729,6 +738,28 @@ static int build_tables(const T *core, int a, int b, int c, const T *R, int64_t 
         hipLaunchKernelGGL(pack_rel_rows_kernel, dim3((unsigned)rows_padded), dim3(256), 0, st, (const rtk_bf16 *)R, a,
                            (int)n_rel, rel_list, n_u_max, n_u_dev, (unsigned char *)r_packed, ks_a);
         int rc = rtk_score_packed_bf16(r_packed, n_u_max, a, core_t, bc, tables, bc, 0, (void *)st);
+        if (rc != RTK_OK) return rc;
+    } else if (sizeof(T) == 4 && r_packed) {
+        // fp32, a > 32 (FB15k: a = 200, 2 690 relations): M[u, n] = sum_a R[rel(u), a] * G[a, n] on the split-fp16
+        // MFMA GEMM of the backward (three f16 MFMAs per k-step on hi/lo halves, one power-of-two scale per operand
+        // from its magnitude bound: the accuracy class the score kernel already works in) -- 2.2x the exact-fp32
+        // MFMA GEMM that built these tables in round 2 (494 us at C4).  The bounds are taken over ALL of R and G,
+        // so a relation's table has the same bits whether it is built for one batch or for every relation.
+        if (xb) hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(1024), 0, st, ga);
+        float *bounds = (float *)r_packed;
+        float *rg = (float *)((unsigned char *)r_packed + 256);
+        int rc = rtk_absmax_f32((const float *)R, n_rel, a, a, bounds, (void *)st);
+        if (rc != RTK_OK) return rc;
+        rc = rtk_absmax_f32((const float *)core, a, bc, bc, bounds + 1, (void *)st);
+        if (rc != RTK_OK) return rc;
+        const float *A = (const float *)R;
+        if (rel_list) {
+            hipLaunchKernelGGL(gather_rel_rows_kernel, dim3((unsigned)n_u_max), dim3(64), 0, st, (const float *)R, a, (int)n_rel,
+                               rel_list, rg);
+            A = rg;
+        }
+        rc = rtk_gemm_sf16_splitk(A, 1, a, bounds, (const float *)core, 0, bc, bounds + 1, tables, bc, n_u_max, bc, a, 1,
+                                  nullptr, 0, (void *)st);
         if (rc != RTK_OK) return rc;
     } else {
         // M[u, n] = sum_a R[rel(u), a] * G[a, n]  as an fp32 MFMA GEMM (bf16 operands widen on load)
@@ -862,8 +893,8 @@ int rtk_query_vectors_bf16_impl(const void *core, int a, int b, int c, const voi
 }
 
 int rtk_relation_tables_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel, float *tables,
-                                 hipStream_t st) {
-    return relation_tables_impl<float>(core, a, b, c, R, n_rel, tables, nullptr, nullptr, st);
+                                 void *r_scratch, hipStream_t st) {
+    return relation_tables_impl<float>(core, a, b, c, R, n_rel, tables, nullptr, r_scratch, st);
 }
 
 int rtk_relation_tables_bf16_impl(const void *core, int a, int b, int c, const void *R, int64_t n_rel, float *tables,

@@ -12,7 +12,6 @@
 #include "rtk_common.h"
 #include <stdlib.h>
 #include "rtk_pack.h"
-#include "rtk_score_bf16_w1.h"
 
 namespace {
 
@@ -241,44 +240,9 @@ int launch_ks(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, f
     return launch_one<KS, 2, MINW, NW>(qp, B, O, N, c, out, ld, o_vec, obf, st);
 }
 
-// deep-K form (rtk_score_bf16_w1.h): one wave per SIMD, 64 entity rows per wave, three-slot LDS ring
-template <int KS, int SG>
-int launch_w1(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
-              bool nts, hipStream_t st) {
-    constexpr size_t smem = 3 * (size_t)KS * 1024;
-    static std::atomic<unsigned long long> ok_nt{0}, ok_pl{0};
-    const void *fn = nts ? reinterpret_cast<const void *>(&rtk_w1::score_bf16_w1_kernel<KS, SG, true>)
-                         : reinterpret_cast<const void *>(&rtk_w1::score_bf16_w1_kernel<KS, SG, false>);
-    const int rc = rtk_ensure_dynamic_lds(fn, (int)smem, nts ? ok_nt : ok_pl, "score_bf16_w1_kernel");
-    if (rc != RTK_OK) return rc;
-    const int n_mt = (int)rtk_cdiv(B, 32);
-    static const int qb_kb = getenv("RTK_BF16_QB_KB") ? atoi(getenv("RTK_BF16_QB_KB")) : 3072;
-    int qb = (int)(((size_t)qb_kb << 10) / (RTK_PACK_HDR + KS * 1024));
-    if (qb < 1) qb = 1;
-    if (qb >= n_mt) qb = n_mt;
-    else qb = (int)rtk_cdiv(n_mt, rtk_cdiv(n_mt, qb));
-    const int64_t units = rtk_cdiv(N, 256) * (int64_t)qb;
-    const unsigned grid = (unsigned)(units < 256 ? units : 256);
-    if (nts)
-        hipLaunchKernelGGL((rtk_w1::score_bf16_w1_kernel<KS, SG, true>), dim3(grid), dim3(256), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
-    else
-        hipLaunchKernelGGL((rtk_w1::score_bf16_w1_kernel<KS, SG, false>), dim3(grid), dim3(256), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
-    return RTK_OK;
-}
-
 template <int KS, int MINW>
 int launch_shape(bool wide, const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld,
                   int sg, bool o_vec, bool obf, hipStream_t st) {
-    if constexpr (KS > 16 && KS % 4 == 0) {
-        static const bool w1_off = getenv("RTK_BF16_NO_W1") != nullptr;      // A/B: round 2's 8-wave form
-        if (wide && !obf && !w1_off) {
-            static const bool nts_off = getenv("RTK_NO_NT_STORES") != nullptr;
-            const bool nts = !nts_off && sg != 1 && (ld * 4) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
-            if (sg == 0) return launch_w1<KS, 0>(qp, B, O, N, c, out, ld, o_vec, nts, st);
-            if (sg == 1) return launch_w1<KS, 1>(qp, B, O, N, c, out, ld, o_vec, nts, st);
-            return launch_w1<KS, 2>(qp, B, O, N, c, out, ld, o_vec, nts, st);
-        }
-    }
     if constexpr (KS > 16) {
         if (wide) return launch_ks<KS, 1, 8>(qp, B, O, N, c, out, ld, sg, o_vec, obf, st);
     }
@@ -307,7 +271,7 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
     const int B = (int)batch, N = (int)n_local;
     // 8-wave workgroups (256 entities share a staged query tile) once the problem fills the chip that way
     static const bool narrow = getenv("RTK_BF16_NARROW") != nullptr;   // A/B: 4-wave workgroups, two per CU
-    const bool wide = !narrow && ks > 16 && ((flags & RTK_SCORE_DEEP_K) || rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256);
+    const bool wide = !narrow && ks > 16 && rtk_cdiv(N, 256) * rtk_cdiv(B, 32) >= 4 * 256;
 #define RTK_KS(K_, W_) case K_: rc = launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, obf, st); break;
     int rc = RTK_OK;
     switch (ks) {

@@ -13,8 +13,8 @@ __device__ unsigned long long g_istamps[4096 * 8];   // ABL bit 7: s_memtime sta
 // SIGMOID: 0 = raw logits, 1 = ocml expf + IEEE divide (torch-CPU formula, ~25 VALU),
 //          2 = 1 / (1 + 2^(-z log2 e)) on v_exp_f32 + v_rcp_f32 (4 VALU, 1 ulp each)
 // LOSS (training forward; reference train.py:79,136 + Dataset.py:51-52): instead of the probability p
-// the epilogue writes x = p - t0 (0 where p is saturated to exactly 1.0f or 0.0f: the reference's autograd returns
-// a zero logit gradient there) -- d BCE / d logit of an entry whose label-smoothed target is the negatives'
+// the epilogue writes x = p - t0 (+0 where p is saturated to exactly 1.0f, -0 where it is 0.0f: the reference's
+// autograd returns a zero logit gradient there) -- d BCE / d logit of an entry whose label-smoothed target is the negatives'
 // t0 = eps / N, up to the factor g / (B N) that the backward applies to the small operands -- and adds the entry's
 // BCE term -(t0 ln p + (1 - t0) ln(1 - p)) (logs on v_log_f32, clamped at -100 like torch) to a per-lane sum that
 // leaves the kernel as ONE double per workgroup in partials[blockIdx.x].  The few positives are patched afterwards
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 if (LOSS) {
                     const float term = t0 * split_clog(pv) + (1.0f - t0) * split_clog(1.0f - pv);
                     if (j < N && row + 4 * h < ep_rows) loss_tile += term;
-                    pv = (pv == 1.0f || pv == 0.0f) ? 0.0f : pv - t0;
+                    pv = (pv == 1.0f) ? 0.0f : ((pv == 0.0f) ? -0.0f : pv - t0);   // (the sign of the zero tells the patch kernel which)
                 }
                 if (off(4)) {
                     if (pv == 12345.678f) out[0] = pv;

@@ -109,48 +109,3 @@ def test_mixed_dtypes_rejected(rt):
     with pytest.raises(RuntimeError, match="share one dtype"):
         rt.score_1vN(core.bfloat16(), R, S, O, torch.tensor([0]).cuda(), torch.tensor([0]).cuda())
 
-
-@pytest.mark.parametrize("shape", [
-    (1000, 5, 70, (3, 512, 512)),        # KS 32; ragged query tile, 4 entity tiles (last one ragged)
-    (257, 3, 33, (2, 310, 310)),         # KS 20 with a ragged last k-step (c % 8 != 0: element-wise fragment loads)
-    (8200, 4, 1000, (2, 384, 384)),      # KS 24; more units than workgroups would need at one tile each
-    (300, 5, 129, (3, 448, 448)),        # KS 28
-    (64, 2, 1, (2, 512, 512)),           # one query, a quarter of an entity tile
-])
-@pytest.mark.parametrize("mode", ["logits", "fast", "exact"])
-def test_deep_k_kernel_against_float64(rt, shape, mode):
-    """rtk_score_bf16_w1.h (one wave per SIMD, 64 entity rows per wave, three-slot LDS ring) forced through
-    RTK_SCORE_DEEP_K at sizes the oracle finishes quickly: same bound as the other bf16 kernels,
-    |dz| <= 2^-8 sum_k |v_k||o_k| against float64 on the bf16-rounded operands -- and within fp32 summation-order
-    noise of the 8-wave kernel on the same packed planes."""
-    from r_tucker_amd import _lib, ops
-    lib = _lib.load()
-    n_ent, n_rel, B, rank = shape
-    c = rank[2]
-    core, R, S, O = gen.make_params(n_ent, n_rel, rank, 21)
-    h, r = gen.make_queries(n_ent, n_rel, B, 21)
-    tb = [bf16_round(x) for x in (core, R, S, O)]
-    d = [t.cuda() for t in tb]
-    hh, rr = torch.from_numpy(h).cuda(), torch.from_numpy(r).cuda()
-    v, qp = ops.query_vectors(d[0], d[1], d[2], hh, rr, packed=True)
-    base = {"logits": 0, "fast": _lib.RTK_SCORE_SIGMOID | _lib.RTK_SCORE_SIGMOID_FAST, "exact": _lib.RTK_SCORE_SIGMOID}[mode]
-    outs = []
-    for extra in (_lib.RTK_SCORE_DEEP_K, 0):
-        out = ops.alloc_scores(B, n_ent, "cuda")
-        out.fill_(-7.0)
-        _lib.check(lib.rtk_score_packed_bf16(qp.data_ptr(), B, c, d[3].data_ptr(), n_ent, out.data_ptr(),
-                                             out.stride(0) if B > 1 else n_ent, base | extra,
-                                             torch.cuda.current_stream().cuda_stream), "rtk_score_packed_bf16")
-        outs.append(out.cpu().numpy().astype(np.float64))
-    deep, wave8 = outs
-    f = [t.float().numpy() for t in tb]
-    ze = orc.logits_exact(f[0], f[1], f[2], f[3], h, r)
-    ve = np.abs(orc.query_vectors_exact(f[0], f[1], f[2], h, r))
-    bound = 2.0 ** -8 * (ve @ np.abs(f[3].astype(np.float64)).T) + 1e-30
-    if mode == "logits":
-        assert np.max(np.abs(deep - ze) / bound) <= 1.0
-        assert np.max(np.abs(deep - wave8) / bound) <= 1e-3          # same products, different fp32 summation order
-    else:
-        pe = 1 / (1 + np.exp(-ze))
-        assert np.max(np.abs(deep - pe) / (0.25 * bound + 3e-7)) <= 1.0     # |dp| <= |dz| / 4
-        assert np.max(np.abs(deep - wave8)) <= 1e-3 * np.max(0.25 * bound) + 3e-7

@@ -233,3 +233,39 @@ def test_captured_step_equals_eager_steps(tmp_path):
         assert (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
     for (a0, a1), (b0, b1) in zip(le, lg):
         assert abs(a0 - b0) <= 1e-5 * abs(a0) and abs(a1 - b1) <= 1e-4 * abs(a1)
+
+
+def test_one_step_turns_the_subject_subspace_by_lr_over_core_scale():
+    """What limits the README recipe under this geometry: the step is the NORMALISED gradient
+    times lr, and the factor component of a tangent vector carries the inverse of the core's Gram matrix, so one step
+    turns a factor's column space by ~ lr / sigma(core).  At the recipe's working point (core norm ~1e3 held down by
+    the regulariser, lr 100-2000) that is a large angle per batch -- the model is a short-memory average of the last
+    few batches; with the core 20x larger and lr 10 the same step is a small perturbation."""
+    import r_tucker_amd as rt
+    from configs.base_config import wn18rr_readme_config
+    from r_tucker_amd import driver
+    from r_tucker_amd.data import Data, KG_dataset
+    data = Data(os.path.join(ROOT, "data", "WN18RR") + "/", reverse=True)
+    train_set = KG_dataset(data, data.train_data, label_smoothing=0.1)
+    flt = rt.DeviceFilter(train_set, "cuda")
+
+    def turn(lr, core_norm):
+        torch.manual_seed(322)
+        cfg = wn18rr_readme_config()
+        cfg.train_cfg.learning_rate = lr
+        model = rt.AsymmetricR_TuckER((len(data.entities), len(data.relations)), cfg.model_cfg.manifold_rank)
+        model.init()
+        if core_norm is not None:
+            with torch.no_grad():
+                model.core.mul_(core_norm / float(model.core.norm()))
+        model.cuda()
+        opt = driver.define_optimizer(model, cfg, "asymmetric", "rsgd")
+        U0 = model.S.weight.detach().clone()
+        driver.train_one_epoch(model, opt, flt, 512, 0.1, regularization_coeff=3e-9, max_batches=1)
+        U1 = model.S.weight.detach()
+        assert _orthonormal(U1) < 5e-5
+        return 1.0 - float(((U0.T @ U1) ** 2).sum()) / U0.shape[1]          # 1 - mean cos^2 of the principal angles
+
+    big, small = turn(100.0, None), turn(10.0, 2.0e4)
+    print(f"\nsubject subspace turned by sin^2 = {big:.3e} (lr 100, init core) / {small:.3e} (lr 10, |core| 2e4)")
+    assert big > 1e-2 and small < 1e-5

@@ -97,7 +97,9 @@ def test_fused_loss_equals_the_three_pass_form(rt, scale, monkeypatch):
     scaled until scores saturate to exactly 1.0f / 0.0f (zero logit gradient there, BCE log clamped at -100): the
     loss agrees to rounding, every gradient to the accuracy of the backward GEMMs."""
     from r_tucker_amd import ops
-    n_ent, n_rel, B, rank = 3003, 7, 70, (4, 48, 48)
+    # (entity rank 224 > 208: the three-pass form's scores come from the same split kernel as the fused form's,
+    # so which entries saturate is decided by the same bits in both)
+    n_ent, n_rel, B, rank = 3003, 7, 70, (3, 224, 224)
     core, R, S, O = gen.make_params(n_ent, n_rel, rank, 43)
     core = core * scale
     rng = np.random.default_rng(43)

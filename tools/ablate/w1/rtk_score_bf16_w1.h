@@ -30,7 +30,10 @@
 
 namespace rtk_w1 {
 
-template <int KS, int SIGMOID, bool NTS>
+// TR: the transposed product with 16-byte stores described above.  TR = false: queries are the A operand, a lane
+// holds one entity column and 16 query rows, sixteen 4-byte stores per tile and block, each instruction two full
+// 128-byte row segments (offsets precomputed once per unit).
+template <int KS, int SIGMOID, bool NTS, bool TR, unsigned ABL = 0>     // ABL: tools/ubench/w1_bench.hip ablations only
 __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
     const unsigned char *__restrict__ q_packed, int B, const rtk_bf16 *__restrict__ O, int N, int c,
     float *__restrict__ out, int64_t ld_out, bool o_vec, int QB) {
@@ -98,6 +101,17 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
         const int ecol = ntile * 256 + wave * 64 + 4 * h;              // first entity of run (rb = 0, g = 0)
         const unsigned voff = (unsigned)(r * ld4 + ecol * 4);
         const bool full = ntile * 256 + 256 <= N;                       // uniform: every column of this tile exists
+        // TR = false: value e of block rb is row 8 (e / 4) + 4 h + e % 4 of the tile, column = the lane's entity
+        unsigned voffs[TR ? 1 : 2][TR ? 1 : 16];
+        if (!TR) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = 8 * (e >> 2) + 4 * h + (e & 3);
+                    voffs[TR ? 0 : rb][TR ? 0 : e] = (jb + 32 * rb < N) ? (unsigned)(row * ld4 + (jb + 32 * rb) * 4) : 0x80000000u;
+                }
+        }
 
 #pragma unroll
         for (int i = 0; i < NLD; ++i) stage_store_one(0, i);
@@ -126,18 +140,26 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
                 if (SIGMOID == 2) pv = __builtin_amdgcn_rcpf(1.0f + ep_d);
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
                 zz[e] = pv;
-                if ((e & 3) == 3) {
+                if (ABL & 1) {                                    // (ablation) no stores: keep the value alive
+                    if (pv == 12345.678f) out[0] = pv;
+                } else if (!TR) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, voffs[TR ? 0 : rb][TR ? 0 : e], 0, NTS ? 2 : 0);
+                } else if ((e & 3) == 3) {
                     const int g = e >> 2;
                     const unsigned o = voff + (unsigned)(rb * 128 + g * 32);
+                    // (element copies first: __builtin_bit_cast applied to an ext-vector ELEMENT lvalue reads element 0,
+                    // clang 19 / ROCm 7.2)
+                    const float p0 = zz[4 * g], p1 = zz[4 * g + 1], p2 = zz[4 * g + 2], p3 = zz[4 * g + 3];
                     if (full) {
-                        const u32x4 q = {__builtin_bit_cast(unsigned, zz[4 * g]), __builtin_bit_cast(unsigned, zz[4 * g + 1]),
-                                         __builtin_bit_cast(unsigned, zz[4 * g + 2]), __builtin_bit_cast(unsigned, zz[4 * g + 3])};
+                        const u32x4 q = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1),
+                                         __builtin_bit_cast(unsigned, p2), __builtin_bit_cast(unsigned, p3)};
                         __builtin_amdgcn_raw_buffer_store_b128(q, ers, o, 0, NTS ? 2 : 0);
                     } else {
+                        const float pq[4] = {p0, p1, p2, p3};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const bool in = ecol + rb * 32 + g * 8 + q < N;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz[4 * g + q]), ers,
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pq[q]), ers,
                                                                   in ? o + 4u * q : 0x80000000u, 0, 0);
                         }
                     }
@@ -164,21 +186,46 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
             const bf16x8 *ln = reinterpret_cast<const bf16x8 *>(lds + nxt * SLOT);
             if (!FIRST) epilogue_begin(mt0 + i - 1);
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // The MFMAs are written in assembly with the entity fragments constrained to the ACCUMULATION half of the
+            // register file ("a"): hipcc parks half of the 256 fragment registers there anyway, but then copies every
+            // fragment back (4 v_accvgpr_read per MFMA) although the matrix pipe reads A/B operands from either half
+            // -- with the copies and the LDS addresses it also spilled there, the wave was VALU-issue-bound at twice
+            // the MFMA time (1.29 ms for raw logits).  Accumulators, query fragments and everything else stay in VGPRs.
+            auto mma = [&](f32x16 &acc, const bf16x8 &q, const bf16x8 &ent, bool first) {
+                if (TR) {
+                    if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(ent), "v"(q));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(ent), "v"(q));
+                } else {
+                    if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(q), "a"(ent));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(q), "a"(ent));
+                }
+            };
+            // 64 pieces over the gaps behind the MFMAs -- except the first gap: the pieces read accumulators whose last
+            // MFMA (written in assembly: the compiler's hazard recogniser does not see it) issued two MFMAs earlier
+            constexpr int GAPS = 2 * KS - 1;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 a = fa[ks % PF];
                 // next fragment: of this tile, or (last PF gaps, behind the barrier) the first ones of the next
-                if (ks + PF < KS) fa[ks % PF] = la[(ks + PF) * 64 + lane];
-                else if (more) fa[ks % PF] = ln[(ks + PF - KS) * 64 + lane];
-                x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[0][ks], a, ks == 0 ? zero : x0, 0, 0, 0);
-                if (!FIRST) piece(y0, y1, 2 * ks);
+                if (!(ABL & 2)) {                                 // (ablation bit 1: the chain re-uses its first fragments)
+                    if (ks + PF < KS) fa[ks % PF] = la[(ks + PF) * 64 + lane];
+                    else if (more) fa[ks % PF] = ln[(ks + PF - KS) * 64 + lane];
+                }
+                mma(x0, a, Bf[0][ks], ks == 0);
+                if (!FIRST) {
+#pragma unroll
+                    for (int pc = (ks == 0 ? 0 : (2 * ks - 1) * 64 / GAPS); pc < (ks == 0 ? 0 : (2 * ks) * 64 / GAPS); ++pc) piece(y0, y1, pc);
+                }
                 // the staged tile i + 1 goes to its slot in the first NLD gaps; then the barrier; then the loads of i + 2
-                if (ks < NLD && more) stage_store_one(nxt, ks);
+                if (ks < NLD && more && !(ABL & 4)) stage_store_one(nxt, ks);
                 __builtin_amdgcn_sched_barrier(0);
-                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[1][ks], a, ks == 0 ? zero : x1, 0, 0, 0);
-                if (!FIRST) piece(y0, y1, 2 * ks + 1);
-                if (ks == NLD) __syncthreads();
-                if (ks > NLD && ks <= 2 * NLD && more2) stage_load_one(mt0 + i + 2, ks - NLD - 1);
+                mma(x1, a, Bf[1][ks], ks == 0);
+                if (!FIRST) {
+#pragma unroll
+                    for (int pc = (2 * ks) * 64 / GAPS; pc < (2 * ks + 1) * 64 / GAPS; ++pc) piece(y0, y1, pc);
+                }
+                if (ks == NLD && !(ABL & 8)) __syncthreads();
+                if (ks > NLD && ks <= 2 * NLD && more2 && !(ABL & 4)) stage_load_one(mt0 + i + 2, ks - NLD - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -190,12 +237,18 @@ __global__ __launch_bounds__(256, 1) void score_bf16_w1_kernel(
             chain(later_t{}, i, accB0, accB1, accA0, accA1);
             chain(later_t{}, i + 1, accA0, accA1, accB0, accB1);
         }
+        auto drain_mfma = [&]() {       // the last MFMAs of the unit (assembly) must have written their results
+#pragma unroll
+            for (int n = 0; n < 5; ++n) asm volatile("s_nop 7");
+        };
         if (i < cnt) {
             chain(later_t{}, i, accB0, accB1, accA0, accA1);
+            drain_mfma();
             epilogue_begin(mt0 + cnt - 1);
 #pragma unroll
             for (int pc = 0; pc < 64; ++pc) piece(accB0, accB1, pc);
         } else {
+            drain_mfma();
             epilogue_begin(mt0 + cnt - 1);
 #pragma unroll
             for (int pc = 0; pc < 64; ++pc) piece(accA0, accA1, pc);

@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--lr", type=float, default=None)
     ap.add_argument("--reg-init", type=float, default=None)
     ap.add_argument("--reg-final", type=float, default=None)
+    ap.add_argument("--const-lr", type=float, default=None, help="hold the learning rate at this value (diagnostic continuation)")
+    ap.add_argument("--extra-epochs", type=int, default=0, help="run this many epochs past the schedule's end (with --const-lr)")
+    ap.add_argument("--save-tag", default=None, help="write log / checkpoint under this tag instead of --tag")
     args = ap.parse_args()
     t_start = time.time()
 
@@ -69,7 +72,7 @@ def main():
     k = args.compress
     cfg = wn18rr_readme_config()
     tc = cfg.train_cfg
-    n_epochs = int(math.ceil(tc.num_epoches / k))
+    n_epochs = int(math.ceil(tc.num_epoches / k)) + args.extra_epochs
     reg_steps = max(1, int(round(tc.num_regularizer_decreasing_steps / k)))
     gamma = tc.scheduler_step ** k
     lr0 = args.lr if args.lr is not None else tc.learning_rate
@@ -100,8 +103,11 @@ def main():
     model.to(dev)
 
     opt = driver.define_optimizer(model, cfg, "asymmetric", "rsgd")
+    def lr_at(e):
+        return args.const_lr if args.const_lr is not None else lr0 * gamma ** e
+
     for g in opt.param_groups:
-        g["lr"] = lr0 * gamma ** epoch0
+        g["lr"] = lr_at(epoch0)
     regulizer = SimpleDecreasingPolicy(reg0, reg_steps, reg1, tc.coeff_adjusting_policy)
     if reg_state is not None:
         regulizer.val, regulizer.cur_step, regulizer._moves = reg_state
@@ -112,8 +118,9 @@ def main():
     val_flt, test_flt = rt.DeviceFilter(val_set, dev), rt.DeviceFilter(test_set, dev)
 
     os.makedirs(args.out, exist_ok=True)
-    log_path = os.path.join(args.out, f"train_{args.tag}.log")
-    ckpt_path = os.path.join(args.out, f"ckpt_{args.tag}.npz")
+    out_tag = args.save_tag or args.tag
+    log_path = os.path.join(args.out, f"train_{out_tag}.log")
+    ckpt_path = os.path.join(args.out, f"ckpt_{out_tag}.npz")
 
     def log(rec):
         with open(log_path, "a") as f:
@@ -164,7 +171,7 @@ def main():
             rec["retraction_health"] = max(health.values())
         log(rec)
         for g in opt.param_groups:
-            g["lr"] = lr0 * gamma ** epoch
+            g["lr"] = lr_at(epoch)
         epoch_times.append(time.time() - te)
         ok = math.isfinite(train_loss) and all(bool(torch.isfinite(p).all()) for p in opt.param_groups[0]["params"])
         if not ok:
@@ -183,7 +190,7 @@ def main():
                 cap[1].drop_graph()
             epoch -= 1
             for g in opt.param_groups:
-                g["lr"] = lr0 * gamma ** epoch
+                g["lr"] = lr_at(epoch)
             continue
         good = snapshot()
     save(epoch)
