@@ -307,7 +307,8 @@ int rtk_rank_metrics_f64(const int32_t *ranks, const double *bce_rows, int64_t b
  *       factor g / (B N); partials_out[0 .. rtk_score_bce_partials()) receive per-workgroup sums of the entries' BCE
  *       terms taken as negatives (unused slots are zeroed).  The B x N matrix is written once, never re-read.
  *   rtk_bce_patch_pos_f32: the known objects of every pair (CSR, as rtk_bce_rows_f32): x <- x - (1 - eps), and
- *       rows_pos_out[d] = the correction of row d's BCE sum.
+ *       rows_pos_out[4 d .. 4 d + 3] = four partial sums of the correction of row d's BCE sum (4 * batch doubles); the positives' logits are recomputed from the fp32
+ *       query vectors v (B, c) and entity rows O (N, c) (x = p - eps / N cannot give back a p far below eps / N).
  *   loss = (sum(partials) + sum(rows_pos)) / (B N);   d loss / d logits = x * g / (B N).
  */
 int rtk_score_bce_partials(void);
@@ -315,7 +316,7 @@ int rtk_score_packed_bce_f32(const void *q_packed, int64_t batch, int c, const f
                              float *x_out, int64_t ld_out, float label_smoothing, double *partials_out, void *stream);
 int rtk_bce_patch_pos_f32(float *X, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
                           const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
-                          double *rows_pos_out, void *stream);
+                          const float *v, const float *O, int c, double *rows_pos_out, void *stream);
 
 /*
  * The exchange step of the entity-sharded path (BASELINE.json north_star: "RCCL all-gather of

@@ -60,7 +60,7 @@ SIGNATURES = {
     "rtk_rank_metrics_f64": (_i, [_p, _p, _i64, _p, _p]),
     "rtk_score_bce_partials": (_i, []),
     "rtk_score_packed_bce_f32": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, C.c_float, _p, _p]),
-    "rtk_bce_patch_pos_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, _p]),
+    "rtk_bce_patch_pos_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, _p, _i, _p, _p]),
     "rtk_comm_unique_id": (_i, [_p]),
     "rtk_comm_init": (_i, [_i, _i, _p, C.POINTER(_p)]),
     "rtk_allgather_scores": (_i, [_p, _p, _sz, _p]),

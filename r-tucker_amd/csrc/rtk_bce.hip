@@ -104,36 +104,48 @@ __global__ __launch_bounds__(256) void bce_grad_all_kernel(float *__restrict__ P
     }
 }
 
-// The positives of the fused training forward (rtk_score_packed_bce_f32 wrote x = p - t0, or 0 where p was saturated,
-// and summed every entry's BCE term as a negative): x <- x - dt, and the row's correction of the loss,
-// -dt (ln p - ln(1 - p)) with p = x + t0.  A stored zero is a saturated score (+0: 1.0f, -0: 0.0f): it stays zero and its correction
-// uses torch's clamp, ln 0 = -100.  One workgroup per row.
-__global__ __launch_bounds__(64) void bce_patch_pos_kernel(float *__restrict__ X, int N, int64_t ld, float t0, float dt,
-                                                           const int64_t *__restrict__ pair_slot,
-                                                           const int64_t *__restrict__ pair_ptr,
-                                                           const int64_t *__restrict__ pair_obj,
-                                                           double *__restrict__ rows_pos) {
-    const int d = blockIdx.x;
+// The positives of the fused training forward (rtk_score_packed_bce_f32 wrote x = p - t0, or a signed zero where p was
+// saturated, and summed every entry's BCE term as a negative): x <- x - dt, and the row's correction of the loss,
+// -dt (ln p - ln(1 - p)).  p cannot be read back from x (p - t0 has lost a p far below t0, and a positive with a very
+// negative logit is exactly where ln p matters), so the logit of each positive is recomputed from the fp32 query vector
+// and entity row -- one wave per row, the 64 lanes share each dot product -- and p from it by the kernel's own formula.  rows_pos holds PATCH_Y = 4 partial sums per row.
+// A stored zero is a score the kernel saw saturated (+0: 1.0f, -0: 0.0f): it stays zero (zero logit gradient, like the
+// reference's autograd) and its correction uses torch's clamp, ln 0 = -100.
+constexpr int PATCH_Y = 4;      // workgroups per row; 4 waves each: 16 positives of a row in flight (hub pairs have hundreds)
+__global__ __launch_bounds__(256) void bce_patch_pos_kernel(float *__restrict__ X, int N, int64_t ld, float t0, float dt,
+                                                            const int64_t *__restrict__ pair_slot,
+                                                            const int64_t *__restrict__ pair_ptr,
+                                                            const int64_t *__restrict__ pair_obj,
+                                                            const float *__restrict__ v, const float *__restrict__ O, int c,
+                                                            double *__restrict__ rows_pos) {
+    __shared__ double s_sum[4];
+    const int d = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *row = X + (int64_t)d * ld;
+    const float *vd = v + (int64_t)d * c;
     const int64_t sl = pair_slot[d];
     float acc = 0.f;
-    for (int64_t i = pair_ptr[sl] + threadIdx.x; i < pair_ptr[sl + 1]; i += 64) {
+    for (int64_t i = pair_ptr[sl] + blockIdx.y * 4 + wave; i < pair_ptr[sl + 1]; i += 4 * PATCH_Y) {
         const int64_t j = pair_obj[i];
-        if (j >= 0 && j < N) {
+        if (j < 0 || j >= N) continue;                   // (uniform over the wave)
+        const float *oj = O + j * c;
+        float z = 0.f;
+        for (int k = lane; k < c; k += 64) z += vd[k] * oj[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+        if (lane == 0) {
             const float x = row[j];
-            if (x == 0.0f) {                             // saturated: +0 = score 1.0f, -0 = score 0.0f
-                acc += (__builtin_bit_cast(unsigned, x) >> 31) ? -dt * 100.0f : dt * 100.0f;   // clog(p) - clog(1 - p) = -+100
+            if (x == 0.0f) {                             // saturated in the kernel: +0 = score 1.0f, -0 = score 0.0f
+                acc += (__builtin_bit_cast(unsigned, x) >> 31) ? -dt * 100.0f : dt * 100.0f;
             } else {
-                const float p = x + t0;
+                const float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
                 acc += dt * (clog(p) - clog(1.0f - p));
                 row[j] = x - dt;
             }
         }
     }
-    double a = (double)acc;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (threadIdx.x == 0) rows_pos[d] = -a;
+    if (lane == 0) s_sum[wave] = (double)acc;
+    __syncthreads();
+    if (threadIdx.x == 0) rows_pos[(int64_t)d * PATCH_Y + blockIdx.y] = -(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
 int check(const char *fn, const float *P, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
@@ -181,13 +193,13 @@ extern "C" int rtk_bce_grad_f32(float *P, int64_t batch, int64_t n_ent, int64_t 
 
 extern "C" int rtk_bce_patch_pos_f32(float *X, int64_t batch, int64_t n_ent, int64_t ld, const int64_t *pair_slot,
                                      const int64_t *pair_ptr, const int64_t *pair_obj, float label_smoothing,
-                                     double *rows_pos_out, void *stream) {
+                                     const float *v, const float *O, int c, double *rows_pos_out, void *stream) {
     int rc = check("rtk_bce_patch_pos_f32", X, batch, n_ent, ld, pair_slot, pair_ptr, pair_obj, label_smoothing);
     if (rc != RTK_OK) return rc;
-    RTK_REQUIRE(rows_pos_out, RTK_ERR_BAD_ARG, "rtk_bce_patch_pos_f32: null output");
-    RTK_REQUIRE(batch < (1ll << 31), RTK_ERR_UNSUPPORTED, "rtk_bce_patch_pos_f32: batch too large");
+    RTK_REQUIRE(rows_pos_out && v && O && c > 0, RTK_ERR_BAD_ARG, "rtk_bce_patch_pos_f32: null operand");
+    RTK_REQUIRE(batch < (1ll << 31) / 4, RTK_ERR_UNSUPPORTED, "rtk_bce_patch_pos_f32: batch too large");
     const float t0 = label_smoothing / (float)n_ent, dt = 1.0f - label_smoothing;
-    hipLaunchKernelGGL(bce_patch_pos_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, X, (int)n_ent, ld, t0, dt,
-                       pair_slot, pair_ptr, pair_obj, rows_pos_out);
+    hipLaunchKernelGGL(bce_patch_pos_kernel, dim3((unsigned)batch, PATCH_Y), dim3(256), 0, (hipStream_t)stream, X, (int)n_ent, ld,
+                       t0, dt, pair_slot, pair_ptr, pair_obj, v, O, c, rows_pos_out);
     return rtk_check_launch("rtk_bce_patch_pos_f32");
 }

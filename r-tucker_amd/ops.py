@@ -476,14 +476,15 @@ class _BceLoss1vN(torch.autograd.Function):
         v, qp = query_vectors(core.detach(), R.detach(), S.detach(), h, r, packed=True)
         X = alloc_scores(B, N, dev)
         partials = torch.empty(lib.rtk_score_bce_partials(), dtype=torch.float64, device=dev)
-        rows_pos = torch.empty(B, dtype=torch.float64, device=dev)
+        rows_pos = torch.empty(4 * B, dtype=torch.float64, device=dev)      # four partial sums per row
         ld = X.stride(0) if B > 1 else N
         with torch.cuda.device(dev):
             sp = _stream_ptr(dev)
             _lib.check(lib.rtk_score_packed_bce_f32(qp.data_ptr(), B, c, O.data_ptr(), N, X.data_ptr(), ld, eps,
                                                     partials.data_ptr(), sp), "rtk_score_packed_bce_f32")
             _lib.check(lib.rtk_bce_patch_pos_f32(X.data_ptr(), B, N, ld, pair_slot.data_ptr(), pair_ptr.data_ptr(),
-                                                 pair_obj.data_ptr(), eps, rows_pos.data_ptr(), sp), "rtk_bce_patch_pos_f32")
+                                                 pair_obj.data_ptr(), eps, v.data_ptr(), O.data_ptr(), c, rows_pos.data_ptr(), sp),
+                       "rtk_bce_patch_pos_f32")
         ctx.save_for_backward(core, R, S, O, h, r, v, X, pair_slot, pair_ptr, pair_obj)
         ctx.eps = eps
         ctx.fused = True

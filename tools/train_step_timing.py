@@ -41,7 +41,17 @@ def b():
     return loss
 
 
-for name, fn in (("score_1vN + nn.BCELoss(dense targets)", a), ("bce_loss_1vN (CSR targets)", b)):
+def c():
+    from r_tucker_amd import ops
+    ops.FUSED_BCE = False
+    try:
+        return b()
+    finally:
+        ops.FUSED_BCE = True
+
+
+for name, fn in (("score_1vN + nn.BCELoss(dense targets)", a), ("bce_loss_1vN (CSR targets, loss fused into the score epilogue)", b),
+                 ("bce_loss_1vN (CSR targets, three passes over the scores: round 2)", c)):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
