@@ -25,12 +25,13 @@ from . import tucker as _tucker
 
 ENABLED = os.environ.get("R_TUCKER_AMD_GRAPH", "0") == "1"     # opt-in: see IN_FLIGHT below and DESIGN.md section 8
 EAGER_STEPS = 2
-# Replays the host may run ahead of the GPU.  A replay is ~700 kernel nodes and takes the GPU ~25 ms but the host
-# ~2 ms to enqueue: unthrottled, a whole epoch (169 replays, ~120 000 packets) sits in the queue.  Free-running
-# replays produced NaN parameters once in ~2 000 steps on this stack (ROCm 7.2, torch 2.10) while the same steps run
-# eagerly, or replayed with a synchronisation after each, did not (tools/debug_graph_nan.py) --
-# so the host waits for replay n - IN_FLIGHT before it launches replay n (an event wait, no device idle time).
-IN_FLIGHT = int(os.environ.get("R_TUCKER_AMD_GRAPH_IN_FLIGHT", "2"))
+# Replays the host may have in flight.  Re-launching this ~700-node graph while its PREVIOUS launch is still executing
+# produced NaN parameters on this stack (ROCm 7.2, torch 2.10): within 40 replays at the WN18RR shape with two in
+# flight (tools/opt_step_timing.py), after ~2 000 in two training runs -- while the same steps eagerly, replayed with
+# one in flight (the host waits for replay n - 1 before it launches replay n), or replayed with torch's own Cholesky
+# kernels in place of the one long single-workgroup kernel, gave the eager numbers.  The wait
+# costs ~0.4 ms of a 22 ms step.
+IN_FLIGHT = int(os.environ.get("R_TUCKER_AMD_GRAPH_IN_FLIGHT", "1"))
 
 
 class CapturedTrainStep:
