@@ -13,13 +13,20 @@
 #include <stdlib.h>
 #include "rtk_pack.h"
 
+#ifndef RTK_BF16_ABL
+#define RTK_BF16_ABL 0          // tools/ablate/bf16 builds only: 1 no stores, 2 no LDS fragment reads, 4 no staging, 8 no barrier
+#endif
+
 namespace {
 
 // NW waves per workgroup, 32 entity rows each: the staged query tile is shared by 32*NW entities,
 // so its L2 -> CU traffic per score is 2*K / (32*NW) bytes (K = 512, NW = 4: 8 B per 4-B score).
 // QB = query tiles per block of the sweep: every workgroup walks the query blocks in the same
 // order, so the chip works on one block (QB tiles, <= ~3 MB) at a time and it stays in the L2s.
-template <int KS, int SIGMOID, int MINW, int NW, bool NTS, bool OBF>
+// V2 (round 3, the 8-wave fp32-score form): ONE accumulator chain per tile whose register set alternates with the
+// finished tile's between tiles (no second chain, no v_pk_add merge, no copy), and the 16 store offsets of a lane
+// computed once per unit instead of one v_add per store -- ~190 issue cycles less VALU per wave and tile.
+template <int KS, int SIGMOID, int MINW, int NW, bool NTS, bool OBF, bool V2 = false>
 __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
     const unsigned char *__restrict__ q_packed, int B, const rtk_bf16 *__restrict__ O, int N, int c,
     float *__restrict__ out, int64_t ld_out, bool o_vec, int QB) {
@@ -105,6 +112,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
             ep_off_last = voff_last;
             asm volatile("" : "+v"(ep_off));
         };
+        unsigned voffs[V2 ? 16 : 1];                 // V2: value e is row 8 (e / 4) + e % 4 (+ 4 h, inside voff) of the tile
+        if (V2) {
+#pragma unroll
+            for (int e = 0; e < (V2 ? 16 : 1); ++e)
+                voffs[e] = (voff == 0x80000000u) ? voff : voff + (unsigned)((8 * (e >> 2) + (e & 3)) * ld4);
+        }
         float ep_d = 1.f, ep_p = 1.f, ep_keep = 0.f;
         auto piece = [&](const f32x16 &z, int pc) {   // 32 pieces: 16 values x {exp half, reciprocal half + store}
             const int e = pc >> 1;
@@ -121,7 +134,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
                 if (SIGMOID == 2) pv = __builtin_amdgcn_rcpf(1.0f + ep_d);   // v_exp_f32 / v_rcp_f32 are 1-ulp
                 if (SIGMOID == 1) pv = 1.0f / ep_d;
                 // NTS (128-B aligned rows): nontemporal -- the scores are written once and not re-read here
-                if (!OBF) {
+                if (RTK_BF16_ABL & 1) {
+                    if (pv == 12345.678f) out[0] = pv;
+                } else if (!OBF && V2) {
+#ifdef RTK_BF16_STORE_AUX       // (tools/ablate/bf16: cache-policy bits of the score stores)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, voffs[V2 ? e : 0], 0, RTK_BF16_STORE_AUX);
+#else
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, voffs[V2 ? e : 0], 0, NTS ? 2 : 0);
+#endif
+                } else if (!OBF) {
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, ep_off, 0, NTS ? 2 : 0);
                     ep_off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
                 } else if (!(e & 1)) {
@@ -146,6 +167,52 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
         __syncthreads();   // previous unit's last tile fully read before restaging buffer 0
         stage_store(0);
         __syncthreads();
+        if constexpr (V2) {
+            constexpr bool STAGE_IN_CHAIN = NW == 8;
+            constexpr int PF = KS < 4 ? KS : (NW == 8 ? 4 : 3);
+            f32x16 accA, accB;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accB[e] = 0.f;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // tile i accumulates in accC while the finished tile i - 1 in accP is turned into probabilities and stored
+            auto iteration = [&](int i, f32x16 &accC, const f32x16 &accP) {
+                const int cur = i & 1;
+                const bool stage = i + 1 < cnt;
+                if (!STAGE_IN_CHAIN && stage) stage_load(mt0 + i + 1);
+                const bf16x8 *la = reinterpret_cast<const bf16x8 *>(lds + cur * TILE_BYTES + RTK_PACK_HDR);
+                epilogue_begin(mt0 + i - 1, i > 0);
+                bf16x8 fa[PF];
+#pragma unroll
+                for (int p = 0; p < PF; ++p) fa[p] = la[p * 64 + lane];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 a = fa[ks % PF];
+                    if (ks + PF < KS && !(RTK_BF16_ABL & 2)) fa[ks % PF] = la[(ks + PF) * 64 + lane];
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bf[ks], ks == 0 ? zero : accC, 0, 0, 0);
+                    if (STAGE_IN_CHAIN && ks < NLD && stage && !(RTK_BF16_ABL & 4)) stage_load_one(mt0 + i + 1, ks);
+#pragma unroll
+                    for (int pc = ks * 32 / KS; pc < (ks + 1) * 32 / KS; ++pc) piece(accP, pc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!(RTK_BF16_ABL & 4)) stage_store(cur ^ 1);
+                if (!(RTK_BF16_ABL & 8)) __syncthreads();
+            };
+            int i = 0;
+            for (; i + 1 < cnt; i += 2) {
+                iteration(i, accA, accB);
+                iteration(i + 1, accB, accA);
+            }
+            if (i < cnt) {
+                iteration(i, accA, accB);
+                epilogue_begin(mt0 + cnt - 1, true);
+#pragma unroll
+                for (int pc = 0; pc < 32; ++pc) piece(accA, pc);
+            } else {
+                epilogue_begin(mt0 + cnt - 1, true);
+#pragma unroll
+                for (int pc = 0; pc < 32; ++pc) piece(accB, pc);
+            }
+        } else {
         f32x16 prev;
 #pragma unroll
         for (int e = 0; e < 16; ++e) prev[e] = 0.f;
@@ -187,17 +254,18 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
         epilogue_begin(mt0 + cnt - 1, true);
 #pragma unroll
         for (int pc = 0; pc < 32; ++pc) piece(prev, pc);
+        }
     }
     }
 }
 
-template <int KS, int SG, int MINW, int NW, bool NTS, bool OBF>
+template <int KS, int SG, int MINW, int NW, bool NTS, bool OBF, bool V2 = false>
 int launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, float *out, int64_t ld, bool o_vec,
               hipStream_t st) {
     constexpr size_t tile = RTK_PACK_HDR + KS * 1024, smem = 2 * tile;
     static std::atomic<unsigned long long> lds_ok{0};
     if (smem > 64 * 1024) {
-        const int rc = rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF>),
+        const int rc = rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF, V2>),
                                               (int)smem, lds_ok, "score_bf16_kernel");
         if (rc != RTK_OK) return rc;
     }
@@ -211,7 +279,7 @@ int launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, f
     else qb = (int)rtk_cdiv(n_mt, rtk_cdiv(n_mt, qb));   // equal blocks
     const int64_t units = rtk_cdiv(N, 32 * NW) * (int64_t)qb;
     const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
-    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
+    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF, V2>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
     return RTK_OK;
 }
 
@@ -220,10 +288,24 @@ int launch_one(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, 
                 bool obf, hipStream_t st) {
     static const bool nts_off = getenv("RTK_NO_NT_STORES") != nullptr;
     const bool nts = !nts_off && (ld * (obf ? 2 : 4)) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
+    static const bool v1 = getenv("RTK_BF16_V1") != nullptr;     // A/B: round 2's two-chain loop in the deep-K form
     if constexpr (SG == 2) {   // bf16 scores: probabilities only (the caller checks)
         if (obf) {
+            // (the same accumulation order as the fp32-score form: bf16 scores = the fp32 ones rounded, bit for bit)
+            if constexpr (NW == 8) {
+                if (!v1) {
+                    if (nts) return launch_nt<KS, SG, MINW, NW, true, true, true>(qp, B, O, N, c, out, ld, o_vec, st);
+                    return launch_nt<KS, SG, MINW, NW, false, true, true>(qp, B, O, N, c, out, ld, o_vec, st);
+                }
+            }
             if (nts) return launch_nt<KS, SG, MINW, NW, true, true>(qp, B, O, N, c, out, ld, o_vec, st);
             return launch_nt<KS, SG, MINW, NW, false, true>(qp, B, O, N, c, out, ld, o_vec, st);
+        }
+    }
+    if constexpr (NW == 8 && SG != 1) {   // deep-K form, fp32 scores: the V2 loop
+        if (!v1) {
+            if (nts) return launch_nt<KS, SG, MINW, NW, true, false, true>(qp, B, O, N, c, out, ld, o_vec, st);
+            return launch_nt<KS, SG, MINW, NW, false, false, true>(qp, B, O, N, c, out, ld, o_vec, st);
         }
     }
     if constexpr (SG != 1) {   // (the exact-logistic variant keeps one form)
@@ -275,10 +357,14 @@ extern "C" int rtk_score_packed_bf16(const void *q_packed, int64_t batch, int c,
 #define RTK_KS(K_, W_) case K_: rc = launch_shape<K_, W_>(wide, qp, B, Ob, N, c, out, ld_out, sg, o_vec, obf, st); break;
     int rc = RTK_OK;
     switch (ks) {
+#ifdef RTK_BF16_HARNESS_KS
+        RTK_KS(RTK_BF16_HARNESS_KS, 2)
+#else
         RTK_KS(1, 2) RTK_KS(2, 2) RTK_KS(3, 2) RTK_KS(4, 2) RTK_KS(5, 2) RTK_KS(6, 2) RTK_KS(7, 2) RTK_KS(8, 2)
         RTK_KS(9, 2) RTK_KS(10, 2) RTK_KS(11, 2) RTK_KS(12, 2) RTK_KS(13, 2) RTK_KS(14, 2) RTK_KS(15, 2) RTK_KS(16, 2)
         RTK_KS(17, 2) RTK_KS(18, 2) RTK_KS(19, 2) RTK_KS(20, 2) RTK_KS(21, 2) RTK_KS(22, 2) RTK_KS(23, 2) RTK_KS(24, 2)
         RTK_KS(25, 2) RTK_KS(26, 2) RTK_KS(27, 2) RTK_KS(28, 2) RTK_KS(29, 2) RTK_KS(30, 2) RTK_KS(31, 2) RTK_KS(32, 2)
+#endif
         default:
             rtk_set_error("rtk_score_packed_bf16: unsupported k-step count %d", ks);
             return RTK_ERR_UNSUPPORTED;
