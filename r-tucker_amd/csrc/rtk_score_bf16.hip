@@ -14,7 +14,8 @@
 #include "rtk_pack.h"
 
 #ifndef RTK_BF16_ABL
-#define RTK_BF16_ABL 0          // tools/ablate/bf16 builds only: 1 no stores, 2 no LDS fragment reads, 4 no staging, 8 no barrier
+#define RTK_BF16_ABL 0          // tools/ablate/bf16 builds only: 1 no stores, 2 no LDS fragment reads, 4 no staging, 8 no barrier,
+                                // 16 every query tile stores into the first tile's rows (16 MB of scores: no HBM write stream)
 #endif
 
 namespace {
@@ -46,12 +47,44 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
     for (int qb0 = 0; qb0 < n_mt; qb0 += QB) {
     const int tq = min(QB, n_mt - qb0);       // query tiles of this block
     const int64_t U = (int64_t)n_nt * tq;
+#if defined(RTK_BF16_SCHED) && RTK_BF16_SCHED == 1
+    // (tools/ablate/bf16) whole entity tiles per workgroup, tile = blockIdx + k * grid: every workgroup is on the same
+    // query tile at the same time (one L2-resident query tile, scores written in long runs per row), unbalanced tail
+    for (int tile_ = blockIdx.x; tile_ < n_nt; tile_ += gridDim.x) {
+    int64_t lin = (int64_t)tile_ * tq;
+    const int64_t lin_end = lin + tq;
+    while (lin < lin_end) {
+#elif defined(RTK_BF16_SCHED) && RTK_BF16_SCHED == 2
+    // whole entity tiles first (tile = blockIdx + k * grid, all query tiles: the workgroups move through the query
+    // tiles in step), then the remaining tiles' (tile, query tile) units cut evenly over the grid
+    const int whole_ = n_nt / (int)gridDim.x, rem0_ = whole_ * (int)gridDim.x;
+    const int64_t Ur_ = (int64_t)(n_nt - rem0_) * tq;
+    int64_t lin = Ur_ * blockIdx.x / gridDim.x;
+    const int64_t lin_end = Ur_ * (blockIdx.x + 1) / gridDim.x;
+    int whole_k_ = 0;
+    {
+    while (whole_k_ < whole_ || lin < lin_end) {
+        int ntile_s, mt0_s, cnt_s;
+        if (whole_k_ < whole_) {
+            ntile_s = blockIdx.x + whole_k_ * gridDim.x; mt0_s = qb0; cnt_s = tq; ++whole_k_;
+        } else {
+            ntile_s = rem0_ + (int)(lin / tq); mt0_s = qb0 + (int)(lin % tq);
+            cnt_s = (int)min((int64_t)(qb0 + tq - mt0_s), lin_end - lin); lin += cnt_s;
+        }
+#define RTK_SCHED2_UNIT 1
+#else
     int64_t lin = U * blockIdx.x / gridDim.x;
     const int64_t lin_end = U * (blockIdx.x + 1) / gridDim.x;
+    {
     while (lin < lin_end) {
+#endif
+#ifdef RTK_SCHED2_UNIT
+        const int ntile = ntile_s, mt0 = mt0_s, cnt = cnt_s;
+#else
         const int ntile = (int)(lin / tq), mt0 = qb0 + (int)(lin % tq);
         const int cnt = (int)min((int64_t)(qb0 + tq - mt0), lin_end - lin);
         lin += cnt;
+#endif
         const int j = ntile * 32 * NW + wave * 32 + r;  // entity (row of O, column of out)
 
         u32x4 stg[NLD];
@@ -106,7 +139,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
         unsigned ep_off = voff, ep_off_last = voff_last;
         auto epilogue_begin = [&](int mt, bool live) {
             const int rows = live ? min(32, B - mt * 32) : 0;
-            ers = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char *>(out) + (int64_t)max(mt, 0) * 32 * ld_out * ES, 0,
+            ers = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char *>(out) + (int64_t)((RTK_BF16_ABL & 16) ? 0 : max(mt, 0)) * 32 * ld_out * ES, 0,
                                                     (unsigned)(rows * ld_out * ES), 0x00020000);
             ep_off = voff;
             ep_off_last = voff_last;
@@ -255,6 +288,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
 #pragma unroll
         for (int pc = 0; pc < 32; ++pc) piece(prev, pc);
         }
+    }
     }
     }
 }
