@@ -87,7 +87,8 @@ def cpu_baseline(gen, n_ent, n_rel, B, rank, pool, budget_s=15.0):
     return {"value": qps, "unit": "queries/s", "cores": th, "kind": "port",
             "sample": f"{n} batches of {B} queries ({dt:.1f} s) of the same workload, torch {torch.__version__} CPU fp32, "
                       f"best of thread counts {[(a, round(b)) for a, b in tried]} ({avail} hardware threads visible); "
-                      f"oracle/score_oracle.py::score_ref"}
+                      f"oracle/score_oracle.py::score_ref; the CPU leg runs all five ops for every batch (no table caching): "
+                      f"the like-for-like GPU figure is per_batch_ms_per_step"}
 
 
 def launch_children(argv, n):
