@@ -23,15 +23,55 @@ import torch
 
 from . import tucker as _tucker
 
-ENABLED = os.environ.get("R_TUCKER_AMD_GRAPH", "0") == "1"     # opt-in: see IN_FLIGHT below and DESIGN.md section 8
+ENABLED = os.environ.get("R_TUCKER_AMD_GRAPH", "0") == "1"     # opt-in: see WAIT below and DESIGN.md section 8
 EAGER_STEPS = 2
-# Replays the host may have in flight.  Re-launching this ~700-node graph while its PREVIOUS launch is still executing
-# produced NaN parameters on this stack (ROCm 7.2, torch 2.10): within 40 replays at the WN18RR shape with two in
-# flight (tools/opt_step_timing.py), after ~2 000 in two training runs -- while the same steps eagerly, replayed with
-# one in flight (the host waits for replay n - 1 before it launches replay n), or replayed with torch's own Cholesky
-# kernels in place of the one long single-workgroup kernel, gave the eager numbers.  The wait
-# costs ~0.4 ms of a 22 ms step.
+# How the host orders replay n behind what is already queued.  On this stack (ROCm 7.2, torch 2.10) a launch of this
+# ~470-node graph onto a stream that still has work queued -- the previous replay, or just the copy of the next batch's
+# ids behind it -- was seen to run concurrently with that work: steps of 9 ms where the kernels alone need 15, loss sums
+# that differ from the eager ones in the 6th digit and NaN parameters within 40 replays (sometimes only after ~2 000;
+# tools/opt_step_timing.py, tools/graph_event_probe.py).  The capture is a single chain (466 nodes,
+# 465 edges, one root: ``describe_graph``), waiting for an event recorded after the previous replay is not enough (the
+# ids copy is already queued behind it), DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 hides it.  Launched onto a DRAINED stream the
+# replays are bit-identical to the eager steps, so "stream" -- hipStreamSynchronize after the ids copy, before the launch
+# -- is the default; it costs nothing once a step is bound by its kernels (15.0 ms replayed, 15.2 ms eager).
+#   stream | device : drain the stream / the device before each launch
+#   event           : wait for an event recorded after replay n - IN_FLIGHT (kept for the experiment; unsafe here)
+WAIT = os.environ.get("R_TUCKER_AMD_GRAPH_WAIT", "stream")
 IN_FLIGHT = int(os.environ.get("R_TUCKER_AMD_GRAPH_IN_FLIGHT", "1"))
+DUMP = os.environ.get("R_TUCKER_AMD_GRAPH_DUMP")               # path: write the captured graph's topology there
+
+
+def describe_graph(raw_graph: int) -> str:
+    """Topology of a captured HIP graph (``hipGraphGetNodes`` / ``hipGraphGetEdges`` through ctypes): node count by
+    type, edge count, roots, and every node with more than one predecessor or successor.  A capture from one stream
+    must be a single chain (edges = nodes - 1, one root, no forks)."""
+    import ctypes
+    from collections import Counter
+    hip = ctypes.CDLL("libamdhip64.so")
+    gh = ctypes.c_void_p(raw_graph)
+    n = ctypes.c_size_t(0)
+    assert hip.hipGraphGetNodes(gh, None, ctypes.byref(n)) == 0
+    nodes = (ctypes.c_void_p * n.value)()
+    assert hip.hipGraphGetNodes(gh, nodes, ctypes.byref(n)) == 0
+    types = []
+    for nd in nodes:
+        t = ctypes.c_int(-1)
+        assert hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(t)) == 0
+        types.append(t.value)
+    e = ctypes.c_size_t(0)
+    assert hip.hipGraphGetEdges(gh, None, None, ctypes.byref(e)) == 0
+    src, dst = (ctypes.c_void_p * max(1, e.value))(), (ctypes.c_void_p * max(1, e.value))()
+    if e.value:
+        assert hip.hipGraphGetEdges(gh, src, dst, ctypes.byref(e)) == 0
+    outdeg, indeg = Counter(src[i] for i in range(e.value)), Counter(dst[i] for i in range(e.value))
+    names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record",
+             10: "mem_alloc", 11: "mem_free"}
+    by_type = Counter(names.get(t, str(t)) for t in types)
+    roots = [nd for nd in nodes if indeg.get(nd, 0) == 0]
+    forks = [(i, names.get(types[i], types[i]), indeg.get(nd, 0), outdeg.get(nd, 0)) for i, nd in enumerate(nodes)
+             if indeg.get(nd, 0) > 1 or outdeg.get(nd, 0) > 1]
+    return (f"nodes {n.value} by type {dict(by_type)}\nedges {e.value}\nroots {len(roots)}\n"
+            f"nodes with in- or out-degree > 1 (index, type, in, out): {forks}\n")
 
 
 class CapturedTrainStep:
@@ -79,18 +119,25 @@ class CapturedTrainStep:
             self.eager_done += 1
             return
         torch.cuda.synchronize(self.dev)
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if DUMP else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._body()
+        if DUMP:
+            with open(DUMP, "w") as f:
+                f.write(describe_graph(g.raw_cuda_graph()))
         self.graph = g              # (the capture itself executed nothing: replay it for this batch)
         self._replay()
 
     def _replay(self):
-        if IN_FLIGHT > 0 and len(self._events) >= IN_FLIGHT:
+        if WAIT == "device":
+            torch.cuda.synchronize(self.dev)
+        elif WAIT == "stream":
+            torch.cuda.current_stream(self.dev).synchronize()
+        elif IN_FLIGHT > 0 and len(self._events) >= IN_FLIGHT:
             self._events.pop(0).synchronize()
         self.graph.replay()
         self.replays += 1
-        if IN_FLIGHT > 0:
+        if WAIT == "event" and IN_FLIGHT > 0:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
             self._events.append(ev)

@@ -26,7 +26,7 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
-from .smalllinalg import spd_inverse, wide_gram
+from .smalllinalg import spd_inverse, spd_inverse_many, wide_gram
 from .tucker import SFTucker, Tucker, _mode_dot, _tn, _unfold
 
 
@@ -88,6 +88,12 @@ def _split_loss(loss_fn):
     if parts is None:
         return loss_fn, None
     return parts
+
+
+def _solve_right_many(mats, grams):
+    """``_solve_right`` for several (matrix, Gram) pairs: Gram matrices of equal size share one factorisation launch."""
+    invs = spd_inverse_many(grams, RCOND.get(mats[0].dtype, 1e-8))
+    return [m @ inv.to(m.dtype) for m, inv in zip(mats, invs)]
 
 
 def _project_out(U: torch.Tensor, M: torch.Tensor) -> torch.Tensor:
@@ -159,7 +165,7 @@ class TuckerRiemannian:
             g_core = g_core + (2.0 * coeff) * G
             loss = loss + coeff * (G * G).sum()
         grams = _point_grams(x, range(len(Us)))
-        deltas = [_solve_right(_project_out(u, g), grams[i]) for i, (u, g) in enumerate(zip(Us, g_fac))]
+        deltas = _solve_right_many([_project_out(u, g) for u, g in zip(Us, g_fac)], grams)
         return TuckerTangentVector(x if x.core is G else Tucker(G, Us), g_core, deltas), loss.detach()
 
     @staticmethod
@@ -171,14 +177,15 @@ class TuckerRiemannian:
         dG = Z.core
         for i, m in enumerate(Ms):
             dG = _mode_dot(dG, m, i)
-        deltas = []
+        ws = []
         for i, (u, v) in enumerate(zip(Us, Z.factors)):
             t = Z.core
             for j, m in enumerate(Ms):
                 if j != i:
                     t = _mode_dot(t, m, j)
             w = v @ (_unfold(t, i) @ _unfold(G, i).transpose(0, 1))           # n_i x r_i
-            deltas.append(_solve_right(_project_out(u, w), _point_grams(x, [i])[0]))
+            ws.append(_project_out(u, w))
+        deltas = _solve_right_many(ws, _point_grams(x, range(len(Us))))
         return TuckerTangentVector(x, dG, deltas)
 
 

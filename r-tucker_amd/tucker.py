@@ -26,7 +26,8 @@ from typing import Sequence
 
 import torch
 
-from .smalllinalg import dominant_left_subspace, gram_factor
+from . import smalllinalg as _sl
+from .smalllinalg import dominant_left_subspace, gram_factor, gram_factor_many
 
 
 def _tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
@@ -92,22 +93,26 @@ def _dbg(what: str, t: torch.Tensor) -> None:
                                  f"first at {bad[0].tolist()}; finite abs max {t[torch.isfinite(t)].abs().max().item() if bad.shape[0] < t.numel() else 'n/a'}")
 
 
+def _orth_tall_many(Ds):
+    """``[(Q, R), ...]`` with ``D = Q R``, Q orthonormal columns, R (k x k, float64) upper triangular, for tall-skinny
+    blocks by two rounds of Cholesky QR: the Gram products are the split-K HIP GEMM on the GPU, the k x k factors and
+    their inverses come from ``smalllinalg.gram_factor_many`` (float64, equilibrated, shifted: no failure path, no host
+    synchronisation; blocks of one width share a launch).  rocSOLVER's Householder ``geqrf`` spends 90 ms on a
+    40 943 x 400 factor; this is four chip-filling GEMMs per block.  A column of zeros stays zero (its row of R is zero)."""
+    f32 = Ds[0].dtype == torch.float32
+    S1 = [_tn(D, D) for D in Ds]
+    for S in S1:
+        _dbg("Gram matrix of the new factor block", S)
+    XR1 = gram_factor_many(S1, shift=3e-6 if f32 else None)          # fp32 Gram: shift at its rounding noise
+    Qs = [D @ X1.to(D.dtype) for D, (X1, _) in zip(Ds, XR1)]
+    for Q in Qs:
+        _dbg("first Cholesky-QR round: Q", Q)
+    XR2 = gram_factor_many([_tn(Q, Q) for Q in Qs], shift=1e-6 if f32 else None)
+    return [(Q @ X2.to(Q.dtype), R2 @ R1) for Q, (_, R1), (X2, R2) in zip(Qs, XR1, XR2)]
+
+
 def _orth_tall(D: torch.Tensor):
-    """``(Q, R)`` with ``D = Q R``, Q orthonormal columns, R (k x k, float64) upper triangular, for a tall-skinny
-    ``D`` by two rounds of Cholesky QR: the Gram products are the split-K HIP GEMM on the GPU, the k x k factor
-    and its inverse come from ``smalllinalg.gram_factor`` (float64, equilibrated, shifted: no failure path, no
-    host synchronisation).  rocSOLVER's Householder ``geqrf`` spends 90 ms on a 40 943 x 400 factor; this is
-    four chip-filling GEMMs.  A column of zeros stays zero (its row of R is zero)."""
-    sh = 3e-6 if D.dtype == torch.float32 else None          # fp32 Gram: shift at its rounding noise
-    S1 = _tn(D, D)
-    _dbg("Gram matrix of the new factor block", S1)
-    X1, R1 = gram_factor(S1, shift=sh)
-    _dbg("first Cholesky-QR round: X", X1)
-    Q = D @ X1.to(D.dtype)
-    _dbg("first Cholesky-QR round: Q", Q)
-    X2, R2 = gram_factor(_tn(Q, Q), shift=None if sh is None else 1e-6)
-    _dbg("second Cholesky-QR round: X", X2)
-    return Q @ X2.to(D.dtype), R2 @ R1
+    return _orth_tall_many([D])[0]
 
 
 def _round_tangent_step(core: torch.Tensor, pairs, mode_factor, ranks):
@@ -127,9 +132,8 @@ def _round_tangent_step(core: torch.Tensor, pairs, mode_factor, ranks):
        over the steps, its triangular factor absorbed into the core."""
     dt = core.dtype
     blocks, bases = [], []
-    for U, D in pairs:
+    for (U, D), (Q, Rd) in zip(pairs, _orth_tall_many([D for _, D in pairs])):   # U^T D = 0 (gauge): [U, Q] is orthonormal
         r = U.shape[1]
-        Q, Rd = _orth_tall(D)                           # U^T D = 0 is the gauge condition: [U, Q] is orthonormal
         k = r + D.shape[1]
         blk = torch.zeros((k, k), dtype=torch.float64, device=core.device)
         blk[:r, :r] = torch.eye(r, dtype=torch.float64, device=core.device)
@@ -139,26 +143,47 @@ def _round_tangent_step(core: torch.Tensor, pairs, mode_factor, ranks):
     c64 = core.double()
     for m, f in enumerate(mode_factor):
         c64 = _mode_dot(c64, blocks[f], m)
-    new_factors = []
-    for f, (U, Q) in enumerate(bases):
-        modes = [m for m, g in enumerate(mode_factor) if g == f]
-        M = torch.cat([_unfold(c64, m) for m in modes], dim=1) if len(modes) > 1 else _unfold(c64, modes[0])
-        _dbg(f"core unfolding of factor {f}", M)
-        W = dominant_left_subspace(M, int(ranks[f]))
-        _dbg(f"subspace basis of factor {f}", W)
-        r = U.shape[1]
-        Wd = W.to(dt)
-        newU = U @ Wd[:r] + Q @ Wd[r:]
-        S = _tn(newU, newU)
-        eye = torch.eye(S.shape[0], dtype=S.dtype, device=S.device)
-        _note_health((S - eye).abs().max())
-        X, Rfix = gram_factor(S, shift=0.0 if dt == torch.float64 else 1e-7)
-        _dbg(f"polish of factor {f}: X", X)
-        newU = newU @ X.to(dt)
-        T = Rfix @ W.transpose(0, 1)                     # (r_new x 2r): truncate, then the polish's triangular factor
-        for m in modes:
-            c64 = _mode_dot(c64, T, m)
-        new_factors.append(newU)
+    modes_of = [[m for m, g in enumerate(mode_factor) if g == f] for f in range(len(bases))]
+    # Factors are truncated in order (sequentially truncated HOSVD), except that consecutive factors which serve ONE
+    # mode each and have the same shapes (the subject and object factors of the asymmetric model) take their bases from
+    # the same core state and go through the iteration, and the polish, as one batch (plain HOSVD among themselves:
+    # the same quasi-optimality bound, half the serial factorisations).
+    groups, f = [], 0
+    while f < len(bases):
+        g = [f]
+        while (_sl.BATCH_EQUAL_SIZES and g[-1] + 1 < len(bases) and len(modes_of[f]) == 1 and len(modes_of[g[-1] + 1]) == 1
+               and bases[g[-1] + 1][0].shape == bases[f][0].shape and bases[g[-1] + 1][1].shape == bases[f][1].shape
+               and int(ranks[g[-1] + 1]) == int(ranks[f]) and c64.shape[modes_of[f][0]] == c64.shape[modes_of[g[-1] + 1][0]]):
+            g.append(g[-1] + 1)
+        groups.append(g)
+        f = g[-1] + 1
+    new_factors = [None] * len(bases)
+    for g in groups:
+        if len(g) == 1:
+            modes = modes_of[g[0]]
+            M = torch.cat([_unfold(c64, m) for m in modes], dim=1) if len(modes) > 1 else _unfold(c64, modes[0])
+            _dbg(f"core unfolding of factor {g[0]}", M)
+            Ws = [dominant_left_subspace(M, int(ranks[g[0]]))]
+        else:
+            M = torch.stack([_unfold(c64, modes_of[f][0]) for f in g])
+            _dbg(f"core unfoldings of factors {g}", M)
+            Ws = list(dominant_left_subspace(M, int(ranks[g[0]])))
+        news = []
+        for f, W in zip(g, Ws):
+            _dbg(f"subspace basis of factor {f}", W)
+            U, Q = bases[f]
+            r = U.shape[1]
+            Wd = W.to(dt)
+            news.append(U @ Wd[:r] + Q @ Wd[r:])
+        Ss = [_tn(nu, nu) for nu in news]
+        for S in Ss:
+            _note_health((S - torch.eye(S.shape[0], dtype=S.dtype, device=S.device)).abs().max())
+        for f, W, nu, (X, Rfix) in zip(g, Ws, news, gram_factor_many(Ss, shift=0.0 if dt == torch.float64 else 1e-7)):
+            _dbg(f"polish of factor {f}: X", X)
+            new_factors[f] = nu @ X.to(dt)
+            T = Rfix @ W.transpose(0, 1)                 # (r_new x 2r): truncate, then the polish's triangular factor
+            for m in modes_of[f]:
+                c64 = _mode_dot(c64, T, m)
     out = c64.to(dt)
     inf = torch.full((), float("inf"), dtype=torch.float64, device=out.device)
     _note_health(torch.where(torch.isfinite(out).all(), torch.zeros_like(inf), inf))

@@ -175,7 +175,7 @@ def main():
         epoch_times.append(time.time() - te)
         ok = math.isfinite(train_loss) and all(bool(torch.isfinite(p).all()) for p in opt.param_groups[0]["params"])
         if not ok:
-            # restore the last good epoch and go on WITHOUT the HIP graph (free-running replays)
+            # restore the last good epoch and go on WITHOUT the HIP graph (launches onto a busy stream)
             log({"event": "non_finite_state", "epoch": epoch, "graph_was_enabled": graphstep.ENABLED, "action": "restore + eager"})
             if not graphstep.ENABLED:
                 break                                   # eager steps produced it: a real numerical problem, stop
