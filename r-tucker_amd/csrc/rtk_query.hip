@@ -519,8 +519,9 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
     const int bpad = (b + 3) & ~3;
     const int cols = (c + W - 1) / W, cpad = cols * W;   // cols <= 256 (host)
     const int ngroups = 256 / cols;
+    const int PG = ngroups > 1 ? ngroups - 1 : 1;
     float *s_rows = smem;                    // QG x bpad
-    float *part = smem + QG * bpad;          // QG x ngroups x cpad, later the finished rows
+    float *part = smem + QG * bpad;          // QG x PG x cpad: partial sums of groups 1.., later (slot 0) the finished rows
     const float *Mq = M + (int64_t)slot * b * c;
 
     if (t < QG) {
@@ -546,12 +547,12 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
     __syncthreads();
 
     const int g = t / cols, col = t - g * cols;
+    float acc[QG][W];
+#pragma unroll
+    for (int q = 0; q < QG; ++q)
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[q][j] = 0.f;
     if (g < ngroups) {
-        float acc[QG][W];
-#pragma unroll
-        for (int q = 0; q < QG; ++q)
-#pragma unroll
-            for (int j = 0; j < W; ++j) acc[q][j] = 0.f;
         constexpr int LB = QG <= 4 ? 20 : 8;  // table rows requested before the first is used (bytes in flight set the rate)
         for (int b0 = g; b0 < b; b0 += ngroups * LB) {
             float x[LB][W];
@@ -581,24 +582,37 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
                 }
             }
         }
+        if (g >= 1) {
 #pragma unroll
-        for (int q = 0; q < QG; ++q)
+            for (int q = 0; q < QG; ++q)
 #pragma unroll
-            for (int j = 0; j < W; ++j) part[(q * ngroups + g) * cpad + col * W + j] = acc[q][j];
+                for (int j = 0; j < W; ++j) part[(q * PG + g - 1) * cpad + col * W + j] = acc[q][j];
+        }
     }
     __syncthreads();
-    // reduce the groups in group order (the per-query kernel's summation order); thread k owns column k
+    // Group 0 keeps its sums in registers and adds the other groups' in group order (0 + p0 + p1 + ...: the
+    // per-query kernel's summation order); the finished row overwrites group 1's partials, column by column by
+    // the thread that has just read them.  (Every group through LDS cost QG x ngroups x c floats: 64 KB at
+    // QG = 16, c = 512 -- one workgroup per CU; now 32 KB.)
     float mx[QG];
 #pragma unroll
-    for (int q = 0; q < QG; ++q) {
-        mx[q] = 0.f;
-        if (q < nq) {
-            for (int k = t; k < c; k += 256) {
-                float x = 0.f;
-                for (int gg = 0; gg < ngroups; ++gg) x += part[(q * ngroups + gg) * cpad + k];
-                part[q * ngroups * cpad + k] = x;
-                mx[q] = fmaxf(mx[q], fabsf(x));
-                if (v_out) v_out[(int64_t)qid[q] * c + k] = x;
+    for (int q = 0; q < QG; ++q) mx[q] = 0.f;
+    if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < QG; ++q) {
+            if (q < nq) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const int k = col * W + j;
+                    if (k < c) {
+                        float x = 0.f;
+                        x += acc[q][j];
+                        for (int gg = 1; gg < ngroups; ++gg) x += part[(q * PG + gg - 1) * cpad + k];
+                        part[q * PG * cpad + k] = x;
+                        mx[q] = fmaxf(mx[q], fabsf(x));
+                        if (v_out) v_out[(int64_t)qid[q] * c + k] = x;
+                    }
+                }
             }
         }
     }
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
             const int row = d & 31;
             if (t == 0) reinterpret_cast<float *>(tile)[row] = 1.0f;
             rtk_bf16 *plane = reinterpret_cast<rtk_bf16 *>(tile + RTK_PACK_HDR);
-            const float *rowv = part + q * ngroups * cpad;
+            const float *rowv = part + q * PG * cpad;
             for (int k = t; k < ksteps * 16; k += 256)
                 plane[rtk_pack_offset(ksteps, k, row)] = rtk_f32_to_bf16((k < c) ? rowv[k] : 0.f);
         }
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
         const int row = d & 31;
         if (t == 0) reinterpret_cast<float *>(tile)[row] = ldexpf(1.0f, -sh);
         _Float16 *planes = reinterpret_cast<_Float16 *>(tile + RTK_PACK_HDR);
-        const float *rowv = part + q * ngroups * cpad;
+        const float *rowv = part + q * PG * cpad;
         for (int k = t; k < ksteps * 16; k += 256) {
             const float x = (k < c) ? rowv[k] * up : 0.f;
             const _Float16 hi = (_Float16)x;
@@ -776,19 +790,33 @@ struct ContractPlan {   // host-side choices of step (2), needed before step (1)
     int QG;
     size_t smem_grouped;
 };
-static ContractPlan plan_contract(int b, int c, int64_t batch, const float *tables) {
+constexpr size_t GROUPED16_LDS_MAX = 78 * 1024;
+static ContractPlan plan_contract(int b, int c, int64_t batch, const float *tables, int64_t n_slots) {
     ContractPlan p;
     p.cvec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(tables) & 15) == 0);
     const int cW = p.cvec ? 4 : 1;
     const int ccols = (c + cW - 1) / cW;
+    // queries per work item (a work item reads its whole b x c table once).  16 is built for A/B only
+    // (RTK_CONTRACT_QG=16): at BASELINE configs[4] -- 8192 queries over 1000 relations, 43 % of the relations with more
+    // than eight queries, 1430 items of 8 against ~1000 of 16, 1 GB of tables -- the step was 2 % SLOWER with 16
+    // (1.441 / 1.461 ms against 1.413 / 1.428 on one box: 212 registers and 64 KB of LDS leave two workgroups per CU)
+    static const int force_qg = getenv("RTK_CONTRACT_QG") ? atoi(getenv("RTK_CONTRACT_QG")) : 0;
     p.QG = batch >= 2048 ? 8 : 4;
+    if (force_qg == 4 || force_qg == 8 || force_qg == 16) p.QG = force_qg;
+    const int ngroups = ccols <= 256 ? 256 / ccols : 1;
+    const int pg = ngroups > 1 ? ngroups - 1 : 1;
     p.smem_grouped = ccols <= 256
-        ? (size_t)((size_t)p.QG * ((b + 3) & ~3) + (size_t)p.QG * (256 / ccols) * ccols * cW) * sizeof(float) : (size_t)-1;
+        ? (size_t)((size_t)p.QG * ((b + 3) & ~3) + (size_t)p.QG * pg * ccols * cW) * sizeof(float) : (size_t)-1;
     static const int force = [] {   // RTK_CONTRACT=perquery|grouped: A/B comparisons
         const char *e = getenv("RTK_CONTRACT");
         return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'g' ? 2 : 0));
     }();
-    p.grouped = p.smem_grouped <= 64 * 1024 && force != 1 && (batch >= 2048 || force == 2);
+    // (16 queries: up to 78 KB of dynamic LDS, two workgroups per CU -- opted in per instantiation in contract_stage)
+    if (p.smem_grouped != (size_t)-1 && p.smem_grouped > GROUPED16_LDS_MAX && p.QG == 16) {
+        p.QG = 8;
+        p.smem_grouped = (size_t)((size_t)p.QG * ((b + 3) & ~3) + (size_t)p.QG * pg * ccols * cW) * sizeof(float);
+    }
+    p.grouped = p.smem_grouped <= (p.QG == 16 ? GROUPED16_LDS_MAX : 64 * 1024 - 1024) && force != 1 && (batch >= 2048 || force == 2);
     return p;
 }
 
@@ -805,8 +833,14 @@ static int contract_stage(const float *tables, int b, int c, const T *S, int64_t
         RTK_REQUIRE(have_groups, RTK_ERR_BAD_ARG, "rtk_query_vectors: grouped contract without groups");
         const unsigned nwg = (unsigned)(batch / cp.QG + (n_slots < batch ? n_slots : batch) + 8);   // upper bound on the work items, rounded up to 8 (flags[2] holds the count)
 #define RTK_CG(V_, Q_) hipLaunchKernelGGL((contract_grouped_kernel<T, V_, Q_>), dim3(nwg), dim3(256), cp.smem_grouped, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, grp_work, grp_order, v_out, (unsigned char *)q_packed, ksteps, flags)
-        if (cp.cvec) { if (cp.QG == 8) RTK_CG(true, 8); else RTK_CG(true, 4); }
-        else { if (cp.QG == 8) RTK_CG(false, 8); else RTK_CG(false, 4); }
+        if (cp.QG == 16) {
+            static std::atomic<unsigned long long> ok_v{0}, ok_s{0};
+            const int rc = cp.cvec ? rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&contract_grouped_kernel<T, true, 16>), (int)GROUPED16_LDS_MAX, ok_v, "contract_grouped_kernel")
+                                   : rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&contract_grouped_kernel<T, false, 16>), (int)GROUPED16_LDS_MAX, ok_s, "contract_grouped_kernel");
+            if (rc != RTK_OK) return rc;
+        }
+        if (cp.cvec) { if (cp.QG == 16) RTK_CG(true, 16); else if (cp.QG == 8) RTK_CG(true, 8); else RTK_CG(true, 4); }
+        else { if (cp.QG == 16) RTK_CG(false, 16); else if (cp.QG == 8) RTK_CG(false, 8); else RTK_CG(false, 4); }
 #undef RTK_CG
         return rtk_check_launch("rtk_query_vectors");
     }
@@ -836,7 +870,7 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, rel_idx, (int)batch, (int)n_rel,
                            ws.slot_of_rel, ws.rel_list, ws.flags);
     }
-    const ContractPlan cp = plan_contract(b, c, batch, ws.tables);
+    const ContractPlan cp = plan_contract(b, c, batch, ws.tables, n_u_max);
     // the slot order is built either way: the per-query kernel uses it to keep a table in one XCD's L2
     // (the per-position (subject, query, slot) records are only read by the per-query contract kernel)
     GroupArgs ga{rel_idx, planned ? ws.slot_of_rel : nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
@@ -865,7 +899,7 @@ template <typename T>
 static int from_tables_impl(const float *tables, int64_t n_rel, int b, int c, const T *S, int64_t n_sub,
                             const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
                             void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
-    const ContractPlan cp = plan_contract(b, c, batch, tables);
+    const ContractPlan cp = plan_contract(b, c, batch, tables, n_rel);
     static const bool order_small = getenv("RTK_FT_ORDER") != nullptr;   // A/B: slot order for the per-query kernel too
     const bool groups = cp.grouped || order_small;
     if (groups) {

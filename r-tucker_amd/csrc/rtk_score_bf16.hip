@@ -18,6 +18,13 @@
                                 // 16 every query tile stores into the first tile's rows (16 MB of scores: no HBM write stream)
 #endif
 
+#ifndef RTK_BF16_ST64
+#define RTK_BF16_ST64 0         // 1 (tools/ablate/bf16 builds only): fp32 scores of the V2 loop leave as 8-byte stores (two neighbouring
+                                // columns of one row per lane, traded between adjacent lanes through DPP): 8 store instructions per
+                                // tile instead of 16.  Parity-correct and 4 % SLOWER at the C5 shard (1.283 / 1.279 ms against
+                                // 1.234 / 1.235 on one box): the store instruction count is not what the stores cost.
+#endif
+
 namespace {
 
 // NW waves per workgroup, 32 entity rows each: the staged query tile is shared by 32*NW entities,
@@ -145,11 +152,22 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
             ep_off_last = voff_last;
             asm volatile("" : "+v"(ep_off));
         };
+        constexpr bool ST64 = RTK_BF16_ST64 && V2 && !OBF;
         unsigned voffs[V2 ? 16 : 1];                 // V2: value e is row 8 (e / 4) + e % 4 (+ 4 h, inside voff) of the tile
-        if (V2) {
+        // ST64: pair p = values (2p, 2p + 1) = two consecutive rows; after the trade the even lane holds columns (c0, c0 + 1)
+        // of the first row, the odd lane those of the second; pair_base = this lane's offset for pair 0
+        const unsigned pair_base = (unsigned)(((4 * h + par) * ld_out + c0) * 4);
+        const bool pair_ok = c0 + 1 < N, pair_last = c0 + 1 == N;          // last: N odd, column c0 alone is real
+        const bool n_odd4 = ST64 && (N & 1);
+        if (V2 && !ST64) {
 #pragma unroll
             for (int e = 0; e < (V2 ? 16 : 1); ++e)
                 voffs[e] = (voff == 0x80000000u) ? voff : voff + (unsigned)((8 * (e >> 2) + (e & 3)) * ld4);
+        }
+        if (ST64) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                voffs[p] = pair_ok ? pair_base + (unsigned)((8 * (p >> 1) + 2 * (p & 1)) * ld4) : 0x80000000u;
         }
         float ep_d = 1.f, ep_p = 1.f, ep_keep = 0.f;
         auto piece = [&](const f32x16 &z, int pc) {   // 32 pieces: 16 values x {exp half, reciprocal half + store}
@@ -169,6 +187,22 @@ __global__ __launch_bounds__(64 * NW, MINW) void score_bf16_kernel(
                 // NTS (128-B aligned rows): nontemporal -- the scores are written once and not re-read here
                 if (RTK_BF16_ABL & 1) {
                     if (pv == 12345.678f) out[0] = pv;
+                } else if (ST64) {
+                    if (!(e & 1)) {
+                        ep_keep = pv;                // first row of the pair: wait for the second
+                    } else {
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        const float send = par ? ep_keep : pv;
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+                        const f32x2_t pr = par ? f32x2_t{recv, pv} : f32x2_t{ep_keep, recv};   // (column c0, column c0 + 1)
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, pr), ers, voffs[e >> 1], 0, NTS ? 2 : 0);
+                        if (n_odd4) {
+                            const int p = e >> 1;
+                            const unsigned vo = pair_last ? pair_base + (unsigned)((8 * (p >> 1) + 2 * (p & 1)) * ld4) : 0x80000000u;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pr[0]), ers, vo, 0, 0);
+                        }
+                    }
                 } else if (!OBF && V2) {
 #ifdef RTK_BF16_STORE_AUX       // (tools/ablate/bf16: cache-policy bits of the score stores)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), ers, voffs[V2 ? e : 0], 0, RTK_BF16_STORE_AUX);

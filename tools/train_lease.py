@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--const-lr", type=float, default=None, help="hold the learning rate at this value (diagnostic continuation)")
     ap.add_argument("--extra-epochs", type=int, default=0, help="run this many epochs past the schedule's end (with --const-lr)")
     ap.add_argument("--save-tag", default=None, help="write log / checkpoint under this tag instead of --tag")
+    ap.add_argument("--epochs", type=int, default=None, help="schedule length (default: the README recipe's 1450)")
+    ap.add_argument("--lr-decay", type=float, default=None, help="per-epoch lr factor (default: the README recipe's .9981)")
+    ap.add_argument("--reg-steps", type=int, default=None)
+    ap.add_argument("--reg-policy", default=None, choices=["exp", "linear"])
     args = ap.parse_args()
     t_start = time.time()
 
@@ -72,9 +76,9 @@ def main():
     k = args.compress
     cfg = wn18rr_readme_config()
     tc = cfg.train_cfg
-    n_epochs = int(math.ceil(tc.num_epoches / k)) + args.extra_epochs
-    reg_steps = max(1, int(round(tc.num_regularizer_decreasing_steps / k)))
-    gamma = tc.scheduler_step ** k
+    n_epochs = int(math.ceil((args.epochs or tc.num_epoches) / k)) + args.extra_epochs
+    reg_steps = max(1, int(round((args.reg_steps or tc.num_regularizer_decreasing_steps) / k)))
+    gamma = (args.lr_decay or tc.scheduler_step) ** k
     lr0 = args.lr if args.lr is not None else tc.learning_rate
     reg0 = args.reg_init if args.reg_init is not None else tc.base_regularization_coeff
     reg1 = args.reg_final if args.reg_final is not None else tc.final_regularization_coeff
@@ -108,7 +112,7 @@ def main():
 
     for g in opt.param_groups:
         g["lr"] = lr_at(epoch0)
-    regulizer = SimpleDecreasingPolicy(reg0, reg_steps, reg1, tc.coeff_adjusting_policy)
+    regulizer = SimpleDecreasingPolicy(reg0, reg_steps, reg1, args.reg_policy or tc.coeff_adjusting_policy)
     if reg_state is not None:
         regulizer.val, regulizer.cur_step, regulizer._moves = reg_state
     train_set = KG_dataset(data, data.train_data, label_smoothing=tc.label_smoothig)
