@@ -377,6 +377,19 @@ def main():
                 step_local(i, cached=False)
             barrier()
             extras["per_batch_ms_per_step"] = (time.perf_counter() - t1) / n_x * 1e3
+        # the score kernel launched back to back (no stage 1 between, ONE event pair around 64 launches): the bracket of
+        # a single launch carries the event pair's own stream time and the dispatch gap in front of the kernel; this
+        # figure is the one that a rocprofv3 kernel trace of the same run reports as the kernel's average duration
+        if True:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(2):
+                e0.record(stream)
+                for _ in range(64):
+                    _lib.check(sp_fn(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch, sflags, sp),
+                               "rtk_score_packed")
+                e1.record(stream)
+                barrier()
+            extras["score_kernel_back_to_back_ms"] = e0.elapsed_time(e1) / 64
         if not bf16 and c <= 512:
             ex = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(12)]
             for e2 in ex:

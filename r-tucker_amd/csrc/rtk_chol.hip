@@ -10,7 +10,10 @@
 // panel and the pivot rows of the inverse in LDS, and applies the same row operations to an identity, so
 // Linv falls out of the same sweep (no second triangular pass, no host round trip, no workspace): the
 // explicit inverse turns every "divide by L" of the step into a plain GEMM.  No failure path: a pivot that
-// cancelled to (or below) 1e-14 of its original diagonal entry is replaced by that floor -- the callers
+// cancelled to (or below) half the diagonal shift (1e-14 of its original diagonal entry without a shift) is replaced by
+// that floor -- exact arithmetic on S >= 0 keeps every pivot above the shift, so the floor only acts on a Gram matrix
+// whose rounding noise exceeds it (an fp32 Gram matrix of 40 943 rows with dependent columns: noise 1e-5 against a
+// shift of 3e-6 gave pivots floored at 1e-14, L entries of 100 behind them and |L^-1| = 1e107) -- the callers
 // equilibrate and shift their matrices, so this only triggers on numerically rank-deficient input -- and
 // nothing is reported to the host (the training driver reads one health word per epoch).
 #include "rtk_common.h"
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
         __syncthreads();
         for (int c = 0; c < w; ++c) {
             __syncthreads();                 // the previous column's updates are visible
-            const double floor_ = 1e-14 * fabs(dg[j0 + c]) + 1e-300;
+            const double floor_ = fmax(1e-14 * fabs(dg[j0 + c]), 0.5 * shift) + 1e-300;
             const double piv = sqrt(fmax(dd[c][c], floor_));     // dd[c][c] itself is left alone (pv holds L[c][c])
             const double ip = 1.0 / piv;
             if (cc == c && r > c && r < w) dd[r][c] *= ip;

@@ -143,6 +143,22 @@ def wide_gram(M: torch.Tensor) -> torch.Tensor:
     return torch.bmm(Mc, Mc.transpose(1, 2)).sum(0)
 
 
+def tall_gram_f64(D: torch.Tensor) -> torch.Tensor:
+    """``D^T D`` of a tall-skinny block (n x k, any precision) accumulated in float64, as a batched product over row
+    chunks.  The products of fp32 entries are exact in float64, so the result is positive semi-definite to 1e-16 -- the
+    fp32 Gram kernel's result is not: over 40 943 rows its rounding noise is ~1e-5 of the diagonal, and a block whose
+    columns are dependent to that level (the new block of a tangent step late in training) then has an INDEFINITE Gram
+    matrix: cancelled pivots, L entries of 100 behind them, |L^-1| = 1e107 and NaN factors at epoch 74 of the
+    reference's default configuration."""
+    n, k = D.shape
+    c = 1024
+    rows = ((n + c - 1) // c) * c
+    Dd = torch.zeros((rows, k), dtype=torch.float64, device=D.device)
+    Dd[:n].copy_(D)
+    Dc = Dd.view(-1, c, k)
+    return torch.bmm(Dc.transpose(1, 2), Dc).sum(0)
+
+
 def _wide_to_square(M: torch.Tensor) -> torch.Tensor:
     """A p x p matrix with the left singular vectors and singular values of a very wide ``M (p x m)``, m >> p: the
     transposed Cholesky factor of ``M M^T`` accumulated in float64 (the relation-mode unfolding of the WN18RR

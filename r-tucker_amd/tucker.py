@@ -95,19 +95,29 @@ def _dbg(what: str, t: torch.Tensor) -> None:
 
 def _orth_tall_many(Ds):
     """``[(Q, R), ...]`` with ``D = Q R``, Q orthonormal columns, R (k x k, float64) upper triangular, for tall-skinny
-    blocks by two rounds of Cholesky QR: the Gram products are the split-K HIP GEMM on the GPU, the k x k factors and
-    their inverses come from ``smalllinalg.gram_factor_many`` (float64, equilibrated, shifted: no failure path, no host
-    synchronisation; blocks of one width share a launch).  rocSOLVER's Householder ``geqrf`` spends 90 ms on a
-    40 943 x 400 factor; this is four chip-filling GEMMs per block.  A column of zeros stays zero (its row of R is zero)."""
+    blocks by two rounds of Cholesky QR: the Gram matrices are accumulated in float64 (a batched product over row
+    chunks), the k x k factors and their inverses come from ``smalllinalg.gram_factor_many`` (float64, equilibrated,
+    shifted: no failure path, no host synchronisation; blocks of one width share a launch).  rocSOLVER's Householder
+    ``geqrf`` spends 90 ms on a 40 943 x 400 factor; this is four chip-filling GEMMs per block.  A column of zeros
+    stays zero (its row of R is zero)."""
     f32 = Ds[0].dtype == torch.float32
-    S1 = [_tn(D, D) for D in Ds]
+    # (float64 accumulation: the block may be rank deficient to fp32 precision, and its Gram matrix must stay positive
+    # semi-definite to well below the shift -- smalllinalg.tall_gram_f64)
+    S1 = [_sl.tall_gram_f64(D) for D in Ds]
     for S in S1:
         _dbg("Gram matrix of the new factor block", S)
-    XR1 = gram_factor_many(S1, shift=3e-6 if f32 else None)          # fp32 Gram: shift at its rounding noise
+    XR1 = gram_factor_many(S1, shift=3e-6 if f32 else None)          # fp32 block: |X| <= 600 / column norm, Q = D X in fp32
     Qs = [D @ X1.to(D.dtype) for D, (X1, _) in zip(Ds, XR1)]
-    for Q in Qs:
-        _dbg("first Cholesky-QR round: Q", Q)
-    XR2 = gram_factor_many([_tn(Q, Q) for Q in Qs], shift=1e-6 if f32 else None)
+    for D, S, (X1, _), Q in zip(Ds, S1, XR1, Qs):
+        if _CHECK and not bool(torch.isfinite(Q).all()):
+            cn = torch.linalg.vector_norm(D.double(), dim=0)
+            raise FloatingPointError(
+                f"retraction: first Cholesky-QR round of a {tuple(D.shape)} block: Q not finite.  column norms of the block: "
+                f"min {cn.min().item():.3e} max {cn.max().item():.3e} last four {cn[-4:].tolist()}; diag of its Gram matrix: min "
+                f"{S.diagonal().min().item():.3e} max {S.diagonal().max().item():.3e}; |X| max {X1.abs().max().item():.3e} at "
+                f"{divmod(int(X1.abs().argmax()), X1.shape[1])}; diag X last four {X1.diagonal()[-4:].tolist()}; "
+                f"non-finite in D {int((~torch.isfinite(D)).sum())}, in S {int((~torch.isfinite(S)).sum())}, in X {int((~torch.isfinite(X1)).sum())}")
+    XR2 = gram_factor_many([_sl.tall_gram_f64(Q) for Q in Qs], shift=1e-6 if f32 else None)
     return [(Q @ X2.to(Q.dtype), R2 @ R1) for Q, (_, R1), (X2, R2) in zip(Qs, XR1, XR2)]
 
 

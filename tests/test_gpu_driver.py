@@ -222,12 +222,16 @@ def test_captured_step_equals_eager_steps(tmp_path):
         replays = step.replays
         return [p.detach().clone() for p in params], losses, replays
 
+    was, dump = graphstep.ENABLED, graphstep.DUMP
     try:
         eager, le, n0 = run(False)
+        graphstep.DUMP = str(tmp_path / "step_graph.txt")          # also write the capture's topology
         graph, lg, n1 = run(True)
     finally:
-        graphstep.ENABLED = True
+        graphstep.ENABLED, graphstep.DUMP = was, dump
     assert n0 == 0 and n1 == 10 - graphstep.EAGER_STEPS
+    topo = open(tmp_path / "step_graph.txt").read()
+    assert "roots 1\n" in topo and topo.rstrip().endswith(": []"), topo      # one chain: nothing may run beside anything
     for a, b in zip(eager, graph):
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
@@ -269,3 +273,27 @@ def test_one_step_turns_the_subject_subspace_by_lr_over_core_scale():
     big, small = turn(100.0, None), turn(10.0, 2.0e4)
     print(f"\nsubject subspace turned by sin^2 = {big:.3e} (lr 100, init core) / {small:.3e} (lr 10, |core| 2e4)")
     assert big > 1e-2 and small < 1e-5
+
+
+def test_cholesky_qr_of_a_rank_deficient_fp32_block_stays_bounded():
+    """The new block of a tangent step late in training: 200 fp32 columns of numerical rank well below 200 and
+    very different sizes.  Its fp32 Gram matrix is indefinite at the 1e-5 level; the factorisation must neither
+    overflow (|L^-1| reached 1e107 when cancelled pivots were floored at 1e-14 instead of at the shift) nor lose
+    D = Q R."""
+    from r_tucker_amd import tucker
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n, k, rk = 40943, 200, 60
+    D = (torch.randn(n, rk, device="cuda", generator=g) @ torch.randn(rk, k, device="cuda", generator=g))
+    D = D * torch.logspace(-2, -6, k, device="cuda")
+    D[:, 37] = 0.0                                                  # and a dead column
+    Q, R = tucker._orth_tall(D)
+    assert torch.isfinite(Q).all() and torch.isfinite(R).all()
+    assert Q.abs().max().item() < 50.0 and (Q[:, 37] == 0).all()
+    rec = Q.double() @ R
+    err = torch.linalg.vector_norm(rec - D.double(), dim=0)
+    ref = torch.linalg.vector_norm(D.double(), dim=0)
+    assert (err <= 2e-3 * ref + 1e-12).all(), (err / ref.clamp_min(1e-30)).max().item()
+    # the independent part is orthonormalised: the leading rk columns of Q (bar the dead one)
+    keep = [j for j in range(rk) if j != 37]
+    G = (Q[:, keep].double().T @ Q[:, keep].double())
+    assert (G - torch.eye(rk - 1, device="cuda", dtype=torch.float64)).abs().max().item() < 1e-3

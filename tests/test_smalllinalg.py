@@ -210,3 +210,43 @@ def test_split_regulariser_equals_autodiff(sym):
     assert abs(la.item() - lb.item()) < 1e-10 * abs(lb.item())
     assert torch.allclose(ga.construct().full(), gb.construct().full(), atol=1e-10)
     assert abs(RegularisedLoss(data, 0.37)(x).item() - whole(x).item()) < 1e-12
+
+
+def test_many_forms_equal_the_single_ones():
+    """gram_factor_many / spd_inverse_many (equal sizes share one batched factorisation) and the batched subspace
+    iteration against the one-matrix calls."""
+    g = torch.Generator().manual_seed(5)
+    mats = []
+    for k in (5, 7, 5, 5, 7):
+        w = torch.randn((3 * k, k), dtype=DT, generator=g)
+        mats.append(w.T @ w)
+    for (X, R), S in zip(sl.gram_factor_many(mats), mats):
+        X1, R1 = sl.gram_factor(S)
+        assert torch.equal(X, X1) and torch.equal(R, R1)
+    for inv, S in zip(sl.spd_inverse_many(mats, 1e-10), mats):
+        assert torch.equal(inv, sl.spd_inverse(S, 1e-10))
+    M = torch.randn((3, 12, 40), dtype=DT, generator=g) * torch.logspace(0, -3, 12, dtype=DT)[None, :, None]
+    Wb = sl.dominant_left_subspace(M, 4)
+    for i in range(3):
+        W1 = sl.dominant_left_subspace(M[i], 4)
+        assert (Wb[i] @ Wb[i].T - W1 @ W1.T).abs().max().item() < 1e-12      # the same subspace
+
+
+def test_round_is_the_same_with_and_without_grouped_factors(monkeypatch):
+    """The S and O factors of the asymmetric model are truncated as one batch from the same core state (plain HOSVD
+    among themselves); one after the other (sequentially truncated) must give a tensor as close to the untruncated
+    one, and an equally orthonormal point."""
+    import test_riemannian as T
+    x = T.point(False, shape=(9, 30, 30), rank=(3, 6, 6))
+    xi, _ = T.random_tangent(x, False, 11)
+    for t in (1e-3, 0.3):
+        moved = ((t * xi) + TuckerRiemannian.TangentVector(x)).construct()
+        full = moved.full()
+        errs = []
+        for grouped in (True, False):
+            monkeypatch.setattr(sl, "BATCH_EQUAL_SIZES", grouped)
+            y = moved.round(x.rank)
+            errs.append((y.full() - full).norm().item())
+            for u in y.factors:
+                assert (u.T @ u - torch.eye(u.shape[1], dtype=DT)).abs().max().item() < 1e-12
+        assert abs(errs[0] - errs[1]) <= 1e-3 * max(errs) + 1e-12 * full.norm().item(), errs

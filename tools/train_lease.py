@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--const-lr", type=float, default=None, help="hold the learning rate at this value (diagnostic continuation)")
     ap.add_argument("--extra-epochs", type=int, default=0, help="run this many epochs past the schedule's end (with --const-lr)")
     ap.add_argument("--save-tag", default=None, help="write log / checkpoint under this tag instead of --tag")
+    ap.add_argument("--debug-from-epoch", type=int, default=None,
+                    help="from this epoch on, check every intermediate of the optimizer step for non-finite values (slow) "
+                         "and stop with the name of the first one")
+    ap.add_argument("--debug-to-epoch", type=int, default=None, help="last epoch of --debug-from-epoch's checks")
     ap.add_argument("--epochs", type=int, default=None, help="schedule length (default: the README recipe's 1450)")
     ap.add_argument("--lr-decay", type=float, default=None, help="per-epoch lr factor (default: the README recipe's .9981)")
     ap.add_argument("--reg-steps", type=int, default=None)
@@ -159,8 +163,21 @@ def main():
         coeff = regulizer.step()
         torch.manual_seed(args.seed * 100003 + epoch)
         lr = opt.param_groups[0]["lr"]
-        train_loss, gnorm = driver.train_one_epoch(model, opt, train_flt, tc.train_batch_size, tc.label_smoothig,
-                                                   regularization_coeff=coeff)
+        if args.debug_from_epoch is not None:
+            from r_tucker_amd import optim as _optim
+            tucker._CHECK = _optim.CHECK_FINITE = (args.debug_from_epoch <= epoch <= (args.debug_to_epoch or 10 ** 9))
+        try:
+            train_loss, gnorm = driver.train_one_epoch(model, opt, train_flt, tc.train_batch_size, tc.label_smoothig,
+                                                       regularization_coeff=coeff)
+        except FloatingPointError as e:
+            sv = [torch.linalg.svdvals(model.core.detach().double().movedim(m, 0).reshape(model.core.shape[m], -1)) for m in range(3)]
+            log({"event": "first_non_finite_intermediate", "epoch": epoch, "what": str(e),
+                 "core_singular_values_first_last": [[float(v[0]), float(v[-3]), float(v[-2]), float(v[-1])] for v in sv]})
+            with torch.no_grad():
+                for p, g in zip(opt.param_groups[0]["params"], good[0]):
+                    p.copy_(g)
+            epoch -= 1
+            break
         t_train = time.time() - te
         vm, vl = driver.evaluate(model, val_set, tc.eval_batch_size, val_flt)
         rec = {"epoch": epoch, "train_loss": train_loss, "grad_norm": gnorm, "lr": lr, "reg_coeff": coeff,
@@ -181,8 +198,13 @@ def main():
         if not ok:
             # restore the last good epoch and go on WITHOUT the HIP graph (launches onto a busy stream)
             log({"event": "non_finite_state", "epoch": epoch, "graph_was_enabled": graphstep.ENABLED, "action": "restore + eager"})
-            if not graphstep.ENABLED:
-                break                                   # eager steps produced it: a real numerical problem, stop
+            if not graphstep.ENABLED:                   # eager steps produced it: a real numerical problem, stop
+                with torch.no_grad():                   # (the checkpoint keeps the last good epoch)
+                    for p, g in zip(opt.param_groups[0]["params"], good[0]):
+                        p.copy_(g)
+                regulizer.val, regulizer.cur_step, regulizer._moves = good[1]
+                epoch -= 1
+                break
             with torch.no_grad():
                 for p, g in zip(opt.param_groups[0]["params"], good[0]):
                     p.copy_(g)
