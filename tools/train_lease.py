@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--debug-from-epoch", type=int, default=None,
                     help="from this epoch on, check every intermediate of the optimizer step for non-finite values (slow) "
                          "and stop with the name of the first one")
+    ap.add_argument("--onecycle", action="store_true",
+                    help="the scheduler the reference's train.py hard-codes (train.py:213-215): OneCycleLR(max_lr=600, "
+                         "total_steps=epochs, pct_start=100/epochs, div_factor=5.5, linear), stepped once per epoch")
     ap.add_argument("--debug-to-epoch", type=int, default=None, help="last epoch of --debug-from-epoch's checks")
     ap.add_argument("--epochs", type=int, default=None, help="schedule length (default: the README recipe's 1450)")
     ap.add_argument("--lr-decay", type=float, default=None, help="per-epoch lr factor (default: the README recipe's .9981)")
@@ -114,8 +117,21 @@ def main():
     def lr_at(e):
         return args.const_lr if args.const_lr is not None else lr0 * gamma ** e
 
-    for g in opt.param_groups:
-        g["lr"] = lr_at(epoch0)
+    sched = None
+    if args.onecycle:
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=600, total_steps=n_epochs, pct_start=100 / n_epochs, div_factor=5.5,
+                                                    cycle_momentum=False, anneal_strategy="linear")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")              # (stepping the schedule before the optimizer: a resumed lease)
+            for _ in range(epoch0):
+                sched.step()
+
+        def lr_at(e):                                    # noqa: F811  (only used by the non-finite restore path)
+            return opt.param_groups[0]["lr"]
+    else:
+        for g in opt.param_groups:
+            g["lr"] = lr_at(epoch0)
     regulizer = SimpleDecreasingPolicy(reg0, reg_steps, reg1, args.reg_policy or tc.coeff_adjusting_policy)
     if reg_state is not None:
         regulizer.val, regulizer.cur_step, regulizer._moves = reg_state
@@ -191,8 +207,12 @@ def main():
         if health:
             rec["retraction_health"] = max(health.values())
         log(rec)
-        for g in opt.param_groups:
-            g["lr"] = lr_at(epoch)
+        if sched is not None:
+            if epoch < n_epochs:
+                sched.step()
+        else:
+            for g in opt.param_groups:
+                g["lr"] = lr_at(epoch)
         epoch_times.append(time.time() - te)
         ok = math.isfinite(train_loss) and all(bool(torch.isfinite(p).all()) for p in opt.param_groups[0]["params"])
         if not ok:
