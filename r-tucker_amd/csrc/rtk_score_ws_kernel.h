@@ -294,7 +294,7 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
 template <int KS, int SIGMOID, bool STAMP, unsigned XP>
 __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict__ q_packed,
                                        const float *__restrict__ O, float *__restrict__ out, int64_t ld_out,
-                                       unsigned char *stg, unsigned char *oreg, int lane, int w4, int ht) {
+                                       unsigned char *stg, unsigned char *oreg, int lane, int w4, int ht, int nts) {
     constexpr int TILE_BYTES = tile_bytes<KS>();
     constexpr int CHUNKS = TILE_BYTES / 16;
     constexpr int NLD = (CHUNKS + 255) / 256;   // staging 16-B chunks per helper thread
@@ -404,10 +404,20 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
 #pragma unroll
                     for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
                     unsigned off = voff;
+                    // nts (128-B aligned rows): nontemporal -- the scores are written once and not re-read here; the
+                    // cache-policy bits are an immediate of the instruction, hence the two copies of the loop
+                    if (nts) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
-                        off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                        for (int e = 0; e < 16; ++e) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 2);
+                            off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
+                            off += ((e & 3) == 3) ? 5u * ld4 : ld4;
+                        }
                     }
                 }
             }
@@ -435,7 +445,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
 template <int KS, int SIGMOID, bool O_VEC, bool STAMP = false, unsigned XP = 0>
 __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
-    float *__restrict__ out, int64_t ld_out, int xcd_remap) {
+    float *__restrict__ out, int64_t ld_out, int xcd_remap, int nts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *const stg = lds;
     unsigned char *const oreg = lds + 2 * tile_bytes<KS>();
@@ -445,7 +455,8 @@ __global__ __launch_bounds__(512, 2) void score_ws_kernel(
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler)
     const int uwave = __builtin_amdgcn_readfirstlane(wave);     // in an SGPR: role tests are scalar branches
     if (uwave < 4) m_role<KS, STAMP, XP, O_VEC, SIGMOID>(sc, q_packed, stg, oreg, lane, uwave & 3, t & 255);
-    else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, uwave & 3, t & 255);
+    else h_role<KS, SIGMOID, STAMP, XP>(sc, q_packed, O, out, ld_out, stg, oreg, lane, uwave & 3, t & 255,
+                                        __builtin_amdgcn_readfirstlane(nts));
 }
 
 }  // namespace rtk_ws

@@ -42,7 +42,7 @@ static int ws_go(const void *qp, int64_t B, int c, const float *O, int64_t N, fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rtk_ws::score_ws_kernel<13, 2, true, true, XP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((rtk_ws::score_ws_kernel<13, 2, true, true, XP>), dim3(grid), dim3(512), smem, (hipStream_t)stream,
-                       (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld, getenv("RTK_WS_XCD") ? atoi(getenv("RTK_WS_XCD")) : 0);
+                       (const unsigned char *)qp, (int)B, O, (int)N, c, out, ld, getenv("RTK_WS_XCD") ? atoi(getenv("RTK_WS_XCD")) : 0, getenv("RTK_WS_NT") ? atoi(getenv("RTK_WS_NT")) : 0);
     return (int)hipGetLastError();
 }
 extern "C" int rtk_ablate_ws(const void *qp, int64_t B, int c, const float *O, int64_t N, float *out, int64_t ld,
