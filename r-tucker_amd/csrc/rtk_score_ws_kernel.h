@@ -288,6 +288,51 @@ __device__ __forceinline__ void m_role(Sched sc, const unsigned char *__restrict
     if (STAMP && lane == 0) g_ws_stamps[(blockIdx.x * 8 + w4) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
+#ifndef RTK_WS_LATE_STORES
+#define RTK_WS_LATE_STORES 1        // 0: round 3's earlier order (stores between the staging loads and the staging write)
+#endif
+// one iteration's score stores / O prefetch of a helper wave (h_role; see the comment at their use)
+#define RTK_WS_SCORES_OUT \
+            if (i >= 2 && !(XP & 2) && !(XP & 16)) { \
+                const int mt = mt0 + i - 2; \
+                const unsigned char *slot = oreg + (i & 1) * EX_BYTES + w4 * 4096; \
+                const int rows = min(32, B - mt * 32); \
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( \
+                    out + (int64_t)mt * 32 * ld_out, 0, (unsigned)(rows * ld_out * 4), 0x00020000); \
+                { \
+                    const f32x4 *exr = reinterpret_cast<const f32x4 *>(slot); \
+                    float zz[16], pp[16]; \
+_Pragma("unroll") \
+                    for (int g = 0; g < 4; ++g) { \
+                        const f32x4 z = exr[g * 64 + lane]; \
+_Pragma("unroll") \
+                        for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q]; \
+                    } \
+_Pragma("unroll") \
+                    for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e]; \
+                    unsigned off = voff; \
+                    if (nts) { \
+_Pragma("unroll") \
+                        for (int e = 0; e < 16; ++e) { \
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 2); \
+                            off += ((e & 3) == 3) ? 5u * ld4 : ld4; \
+                        } \
+                    } else { \
+_Pragma("unroll") \
+                        for (int e = 0; e < 16; ++e) { \
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0); \
+                            off += ((e & 3) == 3) ? 5u * ld4 : ld4; \
+                        } \
+                    } \
+                } \
+            }
+#define RTK_WS_PREFETCH_O \
+            if (i < pf_iters) { \
+_Pragma("unroll") \
+                for (int p = 0; p < (NOR + PFI - 1) / PFI; ++p) \
+                    if (p == i) load_oraw_part(next_tile, p * PFI, min(NOR, (p + 1) * PFI)); \
+            }
+
 // (A/B'd and rejected, round 2: two staging + two storing helper waves, so that the storing waves never wait on
 // vmcnt -- 43.3 us against 42.2 us; two query tiles in flight in the helpers' registers -- 40.0 against 39.4 us;
 // 16-byte score stores from a transposed read of the exchange slot -- 42.1 against 40.4 us.)
@@ -383,52 +428,26 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             // iteration ago -- and its LDS writes come last.
             const bool stage = (i + 1 < cnt) && !(XP & 16);       // (XP & 16, ablation: helpers idle)
             if (stage) stage_load(mt0 + i + 1);
-            if (i >= 2 && !(XP & 2) && !(XP & 16)) { // scores of tile i-2: logistic + stores
-                const int mt = mt0 + i - 2;
-                const unsigned char *slot = oreg + (i & 1) * EX_BYTES + w4 * 4096;
-                const int rows = min(32, B - mt * 32);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    out + (int64_t)mt * 32 * ld_out, 0, (unsigned)(rows * ld_out * 4), 0x00020000);
-                {
-                    const f32x4 *exr = reinterpret_cast<const f32x4 *>(slot);
-                    // stage by stage over all 16 values: written element by element the compiler chains
-                    // mul -> exp -> add -> rcp -> fma -> fma serially through one register (~115 cycles each)
-                    float zz[16], pp[16];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 z = exr[g * 64 + lane];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) zz[4 * g + q] = z[q];
-                    }
-                    // (SIGMOID == 2: the fast logistic was applied by the MFMA waves, see m_role)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) pp[e] = (SIGMOID == 1) ? rtk_sigmoid(zz[e]) : zz[e];
-                    unsigned off = voff;
-                    // nts (128-B aligned rows): nontemporal -- the scores are written once and not re-read here; the
-                    // cache-policy bits are an immediate of the instruction, hence the two copies of the loop
-                    if (nts) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 2);
-                            off += ((e & 3) == 3) ? 5u * ld4 : ld4;   // rows 0,1,2,3,8,9,10,11,16,...
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, 0);
-                            off += ((e & 3) == 3) ? 5u * ld4 : ld4;
-                        }
-                    }
-                }
-            }
-            if (i < pf_iters) {                      // this iteration's share of the next O tile
-#pragma unroll
-                for (int p = 0; p < (NOR + PFI - 1) / PFI; ++p)
-                    if (p == i) load_oraw_part(next_tile, p * PFI, min(NOR, (p + 1) * PFI));
+            // Where the score stores sit in the wave's in-order vector-memory stream decides who waits for their
+            // acknowledgements: hipcc's wait in front of stage_store's LDS writes is vmcnt(<= 5) -- every younger operation
+            // but a few, i.e. THIS iteration's sixteen stores when they are issued between the staging loads and that
+            // wait (the counter is in order; the compiler's bound is not tight: tools/ablate/README "late stores").
+            // RTK_WS_LATE_STORES (default) issues them after stage_store, right before the barrier: the next wait that
+            // covers them is a whole iteration away (same box: 46.9 against 48.2 us per step, kernel 40.1 against 41.6).  The block is a macro so that both orders compile to
+            // the same code apart from its position (as lambdas the same statements cost 19 VGPRs and 268 B of scratch).
+            // scores of tile i-2 (logistic + stores; nts: nontemporal, 128-B aligned rows, the cache-policy bits are an
+            // immediate, hence two copies of the loop), then this iteration's share of the next O tile
+            if constexpr (!RTK_WS_LATE_STORES) {
+                RTK_WS_SCORES_OUT
+                RTK_WS_PREFETCH_O
             }
             if (st) sp[1] = __builtin_amdgcn_s_memtime();
             RTK_TL(1, 6);
             if (stage) stage_store((i + 1) & 1);
+            if constexpr (RTK_WS_LATE_STORES != 0) {     // (the prefetch first: hipcc drains vmcnt in front of its loads)
+                RTK_WS_PREFETCH_O
+                RTK_WS_SCORES_OUT
+            }
             if (st) sp[2] = sp[3] = __builtin_amdgcn_s_memtime();
             RTK_TL(1, 7);
             __syncthreads();
