@@ -431,7 +431,7 @@ __device__ __forceinline__ void h_role(Sched sc, const unsigned char *__restrict
             // Where the score stores sit in the wave's in-order vector-memory stream decides who waits for their
             // acknowledgements: hipcc's wait in front of stage_store's LDS writes is vmcnt(<= 5) -- every younger operation
             // but a few, i.e. THIS iteration's sixteen stores when they are issued between the staging loads and that
-            // wait (the counter is in order; the compiler's bound is not tight: tools/ablate/README "late stores").
+            // wait (the counter is in order; the compiler's bound is not tight: tools/isa_waits.py prints them).
             // RTK_WS_LATE_STORES (default) issues them after stage_store, right before the barrier: the next wait that
             // covers them is a whole iteration away (same box: 46.9 against 48.2 us per step, kernel 40.1 against 41.6).  The block is a macro so that both orders compile to
             // the same code apart from its position (as lambdas the same statements cost 19 VGPRs and 268 B of scratch).
