@@ -250,3 +250,22 @@ def test_round_is_the_same_with_and_without_grouped_factors(monkeypatch):
             for u in y.factors:
                 assert (u.T @ u - torch.eye(u.shape[1], dtype=DT)).abs().max().item() < 1e-12
         assert abs(errs[0] - errs[1]) <= 1e-3 * max(errs) + 1e-12 * full.norm().item(), errs
+
+
+def test_cholesky_qr_of_a_rank_deficient_fp32_block_cpu():
+    """CPU counterpart of tests/test_gpu_driver.py::test_cholesky_qr_of_a_rank_deficient_fp32_block_stays_bounded: the
+    Gram matrices of the Cholesky-QR rounds are accumulated in float64 (tall_gram_f64), so a numerically rank-deficient
+    fp32 block keeps every pivot above the shift: finite, bounded factors and D = Q R."""
+    from r_tucker_amd import tucker
+    g = torch.Generator().manual_seed(7)
+    n, k, rk = 5000, 60, 20
+    D = (torch.randn(n, rk, generator=g) @ torch.randn(rk, k, generator=g)) * torch.logspace(-2, -6, k)
+    D[:, 11] = 0.0
+    S = sl.tall_gram_f64(D)
+    assert S.dtype == torch.float64 and torch.allclose(S, D.double().T @ D.double(), rtol=1e-12, atol=0)
+    Q, R = tucker._orth_tall(D)
+    assert torch.isfinite(Q).all() and torch.isfinite(R).all() and Q.abs().max().item() < 50.0
+    assert (Q[:, 11] == 0).all()
+    err = torch.linalg.vector_norm(Q.double() @ R - D.double(), dim=0)
+    ref = torch.linalg.vector_norm(D.double(), dim=0)
+    assert (err <= 2e-3 * ref + 1e-12).all(), (err / ref.clamp_min(1e-30)).max().item()
