@@ -77,6 +77,15 @@ typedef enum rtk_dtype {
                                   /* returns), ld_out counts bf16 elements; pass the pointer  */
                                   /* through the float* parameter                              */
 
+/* Which fp32 split-fp16 score kernel runs (rtk_score_packed_f32, rtk_score_1vN_f32); 0 = by shape.  The kernels
+ * give the same scores up to the summation order inside a dot product; the hints exist for A/B runs and so that
+ * the tests can put every kernel on every shape.  A hinted kernel that does not cover the shape falls through to
+ * the next one (cg: c <= 208, c % 4 == 0; ws: the same; v3: c <= 512). */
+#define RTK_SCORE_KERNEL_MASK 0x300u
+#define RTK_SCORE_KERNEL_CG 0x100u  /* column-group kernel (csrc/rtk_score_cg_kernel.h), on any entity count    */
+#define RTK_SCORE_KERNEL_WS 0x200u  /* wave-specialised persistent kernel (csrc/rtk_score_ws_kernel.h)           */
+#define RTK_SCORE_KERNEL_V3 0x300u  /* two workgroups per CU, every wave does everything (rtk_score_split_kernel.h) */
+
 int rtk_version(void);
 const char *rtk_last_error_string(void);
 

@@ -20,6 +20,7 @@ RTK_SCORE_SIGMOID = 1
 RTK_SCORE_EXACT_F32 = 2
 RTK_SCORE_SIGMOID_FAST = 4
 RTK_SCORE_OUT_BF16 = 8
+RTK_SCORE_KERNEL_CG, RTK_SCORE_KERNEL_WS, RTK_SCORE_KERNEL_V3 = 0x100, 0x200, 0x300   # kernel hints (A/B, tests)
 
 _p, _i, _i64, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_uint
 

@@ -267,7 +267,7 @@ extern "C" int rtk_score_1vN_f32(const float *core, int a, int b, int c, const f
     if (rc != RTK_OK) return rc;
     if (exact) return rtk_score_f32(ws.v, batch, c, O, n_local, out, ld_out, flags & RTK_SCORE_SIGMOID, stream);
     return rtk_score_packed_f32(ws.q_packed, batch, c, O, n_local, out, ld_out,
-                                flags & (RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST), stream);
+                                flags & (RTK_SCORE_SIGMOID | RTK_SCORE_SIGMOID_FAST | RTK_SCORE_KERNEL_MASK), stream);
 }
 
 extern "C" int rtk_query_vectors_bf16(const void *core, int a, int b, int c, const void *R, int64_t n_rel,

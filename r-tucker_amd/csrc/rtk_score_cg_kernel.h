@@ -1,0 +1,648 @@
+// Split-fp16 score kernel, column-group form (c <= 208, i.e. KS <= 13; fp32 operands).
+//
+//   out[d, j] = logistic( v[d,:] . O[j,:] )          reference: asymmetric/R_TuckER.py:47-48
+//
+// Successor of the wave-specialised kernel (rtk_score_ws_kernel.h) for shapes whose entity columns fill the
+// chip at least four 32-column groups deep.  The entity columns are cut into G = ceil(N/32) GROUPS and the
+// groups are dealt out evenly: a workgroup (512 threads, one per CU, resident for the launch) owns a SET of
+// up to five consecutive groups and scores EVERY query tile against it -- at WN18RR (N = 40 943: 1280 groups,
+// 256 CUs) exactly five groups per CU.  Consequences against the 128-column tiles of the ws kernel:
+//   * O is read from memory exactly once, by exactly one CU, converted once; no tile switch in the middle
+//     of the launch and no remainder sweep (that kernel: 1.25 tiles per CU, 22k of 74k cycles in the tail);
+//   * a staged 32-query tile is used for 160 entity columns instead of 128: the packed query tiles, the
+//     largest stream through the CU's vector-memory path, are re-read 256 x 16 times instead of 320 x 16.
+// Roles (two waves per SIMD, as in the ws kernel):
+//   waves 0-3  "M"  wave w keeps the hi/lo fp16 B fragments of group w of the set in registers and runs that
+//                   group's 3*KS-MFMA chain per query tile.  The FIFTH group is split along K over the four M
+//                   waves: wave w also keeps the fragments of k-steps [S0(w), S1(w)) of group 4 (3-4 of 13) and
+//                   interleaves those 9-12 MFMAs, on a second accumulator, with its own chain (same A fragments);
+//                   the four partial 32x32 accumulators go to LDS raw and are summed -- in wave order, by the
+//                   helper waves -- so every SIMD's matrix pipe carries 48-51 MFMAs per tile-step.  The own
+//                   group's logistic rides in the gaps of the NEXT tile's chain (tile-alternating accumulators).
+//   waves 4-6  "S"  store: the eighty row-segment stores of a tile-step (own groups: tile i-2 from the exchange
+//                   slots; fifth group: tile i-1, four partial accumulators added in wave order, scaled, squashed)
+//                   in twenty units of four, dealt round-robin to the three waves -- all LDS reads of an iteration
+//                   in one batch, then the stores, first thing after the barrier; these waves never wait for memory.
+//   wave 7     "L"  load: streams the packed query tiles global -> registers -> LDS TWO tiles ahead (tile i+2 is
+//                   requested in iteration i and written in iteration i+1 to the buffer the M waves have just
+//                   left); its only vector-memory operations are loads, so hipcc's counted vmcnt waits are
+//                   exact.  (A wave's loads, stores and LDS-DMA share one in-order counter: with loads and stores
+//                   in one wave every wait for a tile also waited for the score stores issued after it.  Measured
+//                   alternatives, tools/ablate/cg_dma: all four helpers loading by LDS-DMA + storing, counted
+//                   waits by hand -- an LDS-DMA piece costs the issuing wave ~150 cycles here, 1.1k per tile-step.)
+// One barrier per tile-step.  Columns of the four own groups are computed by the same instruction sequence as
+// in the ws kernel (bit-identical scores); columns of a fifth group are the sum of four K-range chains.
+//
+// LDS (KS = 13): [misc 640 B: row-factor ring 3 x 128 B, fifth group's column factors 2 x 128 B]
+//                [query tile 0][ X: raw O set (<= 160 rows x c fp32) during the prologue;
+//                                  then query tile 1 | own exchange 2 x 16 KiB | partial sums 2 x 16 KiB ]
+#pragma once
+#include "rtk_common.h"
+#include "rtk_pack.h"
+#include <type_traits>
+
+namespace rtk_cg {
+
+// tools/ablate only (-DRTK_CG_STAMPS): timeline of M wave 0 and H wave 0 of every workgroup,
+// [workgroup][role][event] = code << 56 | s_memtime.  In the product library RTK_CG_TL is empty.
+#ifdef RTK_CG_STAMPS
+static __device__ unsigned long long g_cg_tl[256 * 2 * 64];
+#define RTK_CG_TL(role, code)                                                                                   \
+    do {                                                                                                        \
+        if (tl_on && tl_n < 64) {                                                                               \
+            g_cg_tl[(blockIdx.x * 2 + (role)) * 64 + tl_n] =                                                    \
+                ((unsigned long long)(code) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull);    \
+            ++tl_n;                                                                                             \
+        }                                                                                                       \
+    } while (0)
+#else
+#define RTK_CG_TL(role, code) do { (void)tl_on; (void)tl_n; } while (0)
+#endif
+
+constexpr int NG = 5;                       // groups per set (4 in registers + 1 split along K)
+constexpr int EX_BYTES = 4 * 4 * 64 * 16;   // one exchange buffer: 4 waves x 16 accumulator regs x 64 lanes x f32
+constexpr int MISC_BYTES = 640;
+
+template <int KS>
+__host__ __device__ constexpr int tile_bytes() { return RTK_PACK_HDR + 2 * KS * 1024; }
+
+template <int KS>
+inline size_t lds_bytes(int c) {
+    const size_t sweep = 2 * (size_t)tile_bytes<KS>() + 4 * (size_t)EX_BYTES;
+    const size_t prologue = (size_t)tile_bytes<KS>() + (size_t)NG * 32 * c * 4;
+    return MISC_BYTES + (sweep > prologue ? sweep : prologue);
+}
+
+// shared k-step range of M wave w (the fifth group's chain cut in four): ceil(KS*w/4) .. ceil(KS*(w+1)/4)
+__host__ __device__ constexpr int s_begin(int KS, int w) { return (KS * w + 3) / 4; }
+__host__ __device__ constexpr int s_end(int KS, int w) { return (KS * (w + 1) + 3) / 4; }
+
+struct Geo {
+    int B, N, c, U, n_mt;
+    int64_t ld_out;
+    // set u of U: groups [gb, gb + n_g), n_g <= NG
+    __device__ __forceinline__ void set(int u, int &gb, int &n_g) const {
+        const int64_t G = ((int64_t)N + 31) / 32;
+        gb = (int)(G * u / U);
+        n_g = (int)(G * (u + 1) / U) - gb;
+    }
+};
+
+// All 512 threads: the set's rows of O (contiguous in memory, c % 4 == 0) -> LDS, 16-B pieces, all loads of
+// a thread in flight together; rows past N are zero-filled (their columns are never stored).
+template <int KS>
+__device__ __forceinline__ void load_raw(const float *__restrict__ O, int N, int c, int gb, int n_g,
+                                         unsigned char *raw, int t) {
+    // (through an empty asm: the per-thread piece addresses are otherwise computed once, ahead of the loop over
+    // the sets, and kept -- or spilled -- across the sweep)
+    asm volatile("" : "+v"(t));
+    constexpr int NCH = (NG * 32 * 16 * KS / 4 + 511) / 512;       // 16-B pieces per thread at c = 16*KS
+    const int64_t row0 = (int64_t)gb * 32;
+    const int pieces = n_g * 8 * c;                                  // 32 rows x c floats / 4 per group
+    const int valid = (int)max((int64_t)0, min((int64_t)n_g * 32, (int64_t)N - row0)) * (c / 4);
+    // through a buffer descriptor over the valid rows: a piece past them reads as zero, no branch around
+    // any load (a conditional load makes hipcc wait for the previous one: 17 dependent round trips)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(O + row0 * c), 0, (unsigned)valid * 16u, 0x00020000);
+    u32x4 x[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int pc = i * 512 + t;
+        x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)pc * 16u, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int pc = i * 512 + t;
+        if (pc < pieces) reinterpret_cast<u32x4 *>(raw)[pc] = x[i];
+    }
+}
+
+// One row of the raw set -> hi/lo fp16 B fragments of k-steps [K0, K1) and the row's unscale factor.
+// The scale comes from the maximum over the WHOLE row (all k-steps), whatever range is converted.
+template <int KS, int K0, int K1>
+__device__ __forceinline__ float convert_row(const unsigned char *raw, int row, int c, int h, f16x8 *Bh, f16x8 *Bl) {
+    // (the offsets go through an empty asm: otherwise the loop-invariant fragment addresses are hoisted out
+    // of the sweep loop and stay live across the MFMA chains)
+    int row_off = row * c, h8 = 8 * h;
+    asm volatile("" : "+v"(row_off), "+v"(h8));
+    const float *lrow = reinterpret_cast<const float *>(raw) + row_off;
+    float mx = 0.f;
+    if constexpr (K1 - K0 == KS) {
+        // whole row: read once, keep in registers for the maximum and the conversion
+        f32x4 rw[2 * KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 16 * ks + h8;                  // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
+            rw[2 * ks] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
+            rw[2 * ks + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 16 * ks + h8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(k + 4 <= c)) rw[2 * ks][q] = 0.f;
+                if (!(k + 8 <= c)) rw[2 * ks + 1][q] = 0.f;
+                mx = fmaxf(mx, fmaxf(fabsf(rw[2 * ks][q]), fabsf(rw[2 * ks + 1][q])));
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const int sh = rtk_pack_shift(mx);
+        const float up = ldexpf(1.0f, sh);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float y0 = rw[2 * ks][q] * up, y1 = rw[2 * ks + 1][q] * up;
+                const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+                Bh[ks][q] = h0;
+                Bh[ks][4 + q] = h1;
+                Bl[ks][q] = (_Float16)(y0 - (float)h0);
+                Bl[ks][4 + q] = (_Float16)(y1 - (float)h1);
+            }
+        }
+        return ldexpf(1.0f, -sh);
+    } else {
+        static_assert(K1 - K0 == KS, "whole rows only: a k-range goes through convert_range");
+        return 0.f;
+    }
+}
+
+// k-steps [K0, K1) of one row -> hi/lo fp16 B fragments, with the row's scale `up` given (the helper waves
+// find the maximum of the fifth group's rows while the M waves convert their own groups)
+template <int KS, int K0, int K1>
+__device__ __forceinline__ void convert_range(const unsigned char *raw, int row, int c, int h, float up, f16x8 *Bh, f16x8 *Bl) {
+    int row_off = row * c, h8 = 8 * h;
+    asm volatile("" : "+v"(row_off), "+v"(h8));
+    const float *lrow = reinterpret_cast<const float *>(raw) + row_off;
+    f32x4 rw[2 * (K1 - K0) + 1];
+#pragma unroll
+    for (int ks = K0; ks < K1; ++ks) {
+        const int k = 16 * ks + h8;
+        rw[2 * (ks - K0)] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
+        rw[2 * (ks - K0) + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
+    }
+#pragma unroll
+    for (int ks = K0; ks < K1; ++ks) {
+        const int k = 16 * ks + h8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float y0 = (k + 4 <= c) ? rw[2 * (ks - K0)][q] * up : 0.f, y1 = (k + 8 <= c) ? rw[2 * (ks - K0) + 1][q] * up : 0.f;
+            const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+            Bh[ks - K0][q] = h0;
+            Bh[ks - K0][4 + q] = h1;
+            Bl[ks - K0][q] = (_Float16)(y0 - (float)h0);
+            Bl[ks - K0][4 + q] = (_Float16)(y1 - (float)h1);
+        }
+    }
+}
+
+struct LdsMap {
+    unsigned char *hdr;      // 3 x 128 B: row factors of the query tiles t % 3 (they outlive the tile's buffer)
+    float *uso5, *up5;       // 2 x 32 floats: unscale / scale factors (powers of two) of the fifth group's columns
+    unsigned char *stg0, *stg1;   // query tile t in buffer t & 1
+    unsigned char *raw;      // prologue: the set's rows of O (over buffer 1 and the exchange)
+    unsigned char *exo;      // 2 x EX_BYTES: own accumulators (probabilities) of tile t & 1
+    unsigned char *exp5;     // 2 x EX_BYTES: the four partial accumulators of the fifth group, tile t & 1
+    template <int KS>
+    __device__ __forceinline__ void init(unsigned char *lds) {
+        hdr = lds;
+        uso5 = reinterpret_cast<float *>(lds + 384);
+        up5 = reinterpret_cast<float *>(lds + 512);
+        stg0 = lds + MISC_BYTES;
+        raw = stg0 + tile_bytes<KS>();
+        stg1 = raw;
+        exo = stg1 + tile_bytes<KS>();
+        exp5 = exo + 2 * EX_BYTES;
+    }
+};
+
+// ---- M role: the sweep over the query tiles with the set's fragments in registers --------------------------
+template <int KS, int W4, int SIGMOID, bool EXTRA>
+__device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, const f16x8 (&Bh)[KS], const f16x8 (&Bl)[KS],
+                                        const f16x8 *Sh, const f16x8 *Sl, float us_o, bool tl_on, int &tl_n) {
+    constexpr int PF = KS < 3 ? KS : 3;         // A-fragment prefetch distance (k-steps)
+    constexpr int S0 = s_begin(KS, W4), S1 = s_end(KS, W4), NS = EXTRA ? S1 - S0 : 0;
+    constexpr int NGAP = 3 * KS + 3 * NS;       // MFMAs (= gaps) of one chain
+    // the partial accumulator is complete after the last shared MFMA (gap 3*S1 + 3*NS - 1); its four 16-B
+    // writes take the gaps from three later on (past the chain for the wave whose range ends the chain)
+    constexpr int PW0 = !EXTRA ? (1 << 20) : (NS > 0 ? 3 * S1 + 3 * NS + 2 : 32);
+    constexpr int GEND = EXTRA ? (PW0 + 4 > 36 ? PW0 + 4 : 36) : 32;
+    constexpr bool MSIG = SIGMOID == 2;
+    const int h = lane >> 5;
+    const float kfac = MSIG ? us_o * -1.4426950408889634f : us_o;
+    float ee = 0.f;
+    f32x16 accA, accB, accS;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accB[e] = 0.f, accS[e] = 0.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // PAR = i & 1 as a compile-time constant (the loop below is unrolled by two): every LDS address of an
+    // iteration but the row-factor slot is then `lane * 16 + constant`
+    // CHAIN (tile i exists) and PIECES (tile i-1 exists) are compile-time too: the steady-state loop below has
+    // no branch in it.  (With `if (i < cnt)` / `if (i > 0)` inside one body the accumulators met at control-flow
+    // joins and hipcc moved them between register sets: ~50 v_mov per tile-step in one of the two bodies.)
+    auto iteration = [&](auto par_c, auto chain_c, auto pieces_c, int i, f32x16 &accC, f32x16 &accP) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool chain = decltype(chain_c)::value, pieces = decltype(pieces_c)::value;
+        f32x4 *exw = reinterpret_cast<f32x4 *>(L.exo + (PAR ^ 1) * EX_BYTES + W4 * 4096);   // own slot of tile i-1
+        f32x4 *exs = reinterpret_cast<f32x4 *>(L.exp5 + PAR * EX_BYTES + W4 * 4096);        // partial slot of tile i
+        const float *rfp = reinterpret_cast<const float *>(L.hdr + ((i + 2) % 3) * 128) + 4 * h;  // row factors of tile i-1
+        f32x4 rfq[2];
+        // gap g of the chain.  Own hand-over of tile i-1: piece p = 2e / 2e+1 turns accumulator element e into a
+        // probability in place (one multiply pair + v_exp_f32, then one add + v_rcp_f32), every fourth element
+        // completes a 16-B write to the exchange slot; the row factors of element group e/4 are fetched eight
+        // pieces ahead.  Gaps PW0..PW0+3 carry the partial accumulator of tile i instead.
+        auto gap = [&](int g) {
+            if (EXTRA && g >= PW0 && g < PW0 + 4) {
+                if (chain) {
+                    const int q = g - PW0;
+                    exs[q * 64 + lane] = f32x4{accS[4 * q], accS[4 * q + 1], accS[4 * q + 2], accS[4 * q + 3]};
+                }
+                return;
+            }
+            const int p = g - ((EXTRA && g >= PW0 + 4) ? 4 : 0);
+            if (p >= 32 || !pieces) return;
+            const int e = p >> 1, eg = e >> 2;
+            if ((p & 7) == 1 && eg < 3) rfq[(eg + 1) & 1] = *reinterpret_cast<const f32x4 *>(rfp + 8 * (eg + 1));
+            if (MSIG) {
+                if (!(p & 1)) {
+                    ee = __builtin_amdgcn_exp2f(accP[e] * rfq[eg & 1][e & 3] * kfac);
+                } else {
+                    accP[e] = __builtin_amdgcn_rcpf(1.0f + ee);
+                    if ((e & 3) == 3) exw[eg * 64 + lane] = f32x4{accP[e - 3], accP[e - 2], accP[e - 1], accP[e]};
+                }
+            } else if ((p & 7) == 0) {               // logits / exact logistic: unscale only, 4 values per piece
+                f32x4 z;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[q] = accP[4 * eg + q] * rfq[eg & 1][q] * kfac;
+                exw[eg * 64 + lane] = z;
+            }
+        };
+        if (pieces) rfq[0] = *reinterpret_cast<const f32x4 *>(rfp);
+        if constexpr (chain) {
+            const unsigned char *tile = PAR ? L.stg1 : L.stg0;
+            const f16x8 *lh = reinterpret_cast<const f16x8 *>(tile + RTK_PACK_HDR);
+            const f16x8 *ll = lh + KS * 64;
+            f16x8 fa[PF], fl[PF];                // A fragments PF k-steps ahead
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                fa[p] = lh[p * 64 + lane];
+                fl[p] = ll[p * 64 + lane];
+            }
+            int g = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 ah = fa[ks % PF], al = fl[ks % PF];
+                if (ks + PF < KS) {
+                    fa[ks % PF] = lh[(ks + PF) * 64 + lane];
+                    fl[ks % PF] = ll[(ks + PF) * 64 + lane];
+                }
+                const bool sh = EXTRA && ks >= S0 && ks < S1;
+                // sched_barrier(0) pins the written order MFMA / piece / MFMA / piece (see the ws kernel)
+                __builtin_amdgcn_sched_barrier(0);
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], ks == 0 ? zero : accC, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                gap(g++);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sh) {
+                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Sh[ks - S0], ks == S0 ? zero : accS, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    gap(g++);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], accC, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                gap(g++);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sh) {
+                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Sl[ks - S0], accS, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    gap(g++);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], accC, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                gap(g++);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sh) {
+                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Sh[ks - S0], accS, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    gap(g++);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int gg = NGAP; gg < GEND; ++gg) gap(gg);   // what did not fit the chain
+        } else if constexpr (pieces) {           // drain: hand over the last tile
+#pragma unroll
+            for (int gg = 0; gg < 32; ++gg) gap(gg + ((EXTRA && gg >= PW0) ? 4 : 0));
+        }
+        RTK_CG_TL(0, 6);
+        __syncthreads();
+        RTK_CG_TL(0, 5);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+    iteration(P0{}, T{}, F{}, 0, accA, accB);                     // tile 0: chain only
+    int i = 1;
+    for (; i + 1 < cnt; i += 2) {                                 // steady state, two tiles per trip (i odd)
+        iteration(P1{}, T{}, T{}, i, accB, accA);
+        iteration(P0{}, T{}, T{}, i + 1, accA, accB);
+    }
+    if (i < cnt) {                                                // cnt even: one more chain, its result in accB
+        iteration(P1{}, T{}, T{}, i, accB, accA);
+        iteration(P0{}, F{}, T{}, i + 1, accA, accB);
+        iteration(P1{}, F{}, F{}, i + 2, accB, accA);
+    } else {                                                      // cnt odd: the last tile is in accA
+        iteration(P1{}, F{}, T{}, i, accB, accA);
+        iteration(P0{}, F{}, F{}, i + 1, accA, accB);
+    }
+}
+
+template <int KS, int W4, int SIGMOID>
+__device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__ O, const LdsMap &L, int lane, int t) {
+    constexpr int S0 = s_begin(KS, W4), S1 = s_end(KS, W4), NS = S1 - S0;
+    const int r = lane & 31, h = lane >> 5, c = geo.c;
+    const bool tl_on = W4 == 0 && lane == 0;
+    int tl_n = 0;
+    for (int u = blockIdx.x; u < geo.U; u += gridDim.x) {
+        int gb, n_g;
+        geo.set(u, gb, n_g);
+        RTK_CG_TL(0, 1);
+        load_raw<KS>(O, geo.N, c, gb, n_g, L.raw, t);
+        __syncthreads();                             // S1: the raw set is in LDS
+        RTK_CG_TL(0, 2);
+        const bool own = W4 < n_g;
+        f16x8 Bh[KS], Bl[KS], Sh[NS > 0 ? NS : 1], Sl[NS > 0 ? NS : 1];
+        float us_o = 0.f;
+        if (own) us_o = convert_row<KS, 0, KS>(L.raw, W4 * 32 + r, c, h, Bh, Bl);
+        RTK_CG_TL(0, 7);
+        __syncthreads();                             // S1b: the helper waves have the fifth group's row scales
+        if (n_g == NG) convert_range<KS, S0, S1>(L.raw, 4 * 32 + r, c, h, L.up5[r], Sh, Sl);
+        RTK_CG_TL(0, 3);
+        __syncthreads();                             // S2: query tile 0 staged, the raw region is free
+        RTK_CG_TL(0, 4);
+        if (!own) {
+            for (int i = 0; i < geo.n_mt + 2; ++i) __syncthreads();
+        } else if (n_g == NG) {
+            m_sweep<KS, W4, SIGMOID, true>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, tl_on, tl_n);
+        } else {
+            m_sweep<KS, W4, SIGMOID, false>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, tl_on, tl_n);
+        }
+    }
+}
+
+// ---- H role ------------------------------------------------------------------------------------------------
+template <int AUX>
+__device__ __forceinline__ void store_own(const float (&pp)[16], __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned ld4) {
+    unsigned off = voff;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, AUX);
+        off += ((e & 3) == 3) ? 5u * ld4 : ld4;
+    }
+}
+template <int AUX>
+__device__ __forceinline__ void store_five(const float (&p5)[4], __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned ld4) {
+    unsigned off = voff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p5[q]), rs, off, 0, AUX);
+        off += ld4;
+    }
+}
+
+// the fifth group's row maxima -> power-of-two scale and its inverse (all 256 helper threads, between S1 and
+// S1b, while the M waves convert their own groups): eight lanes per row, 16-B pieces
+__device__ __forceinline__ void fifth_row_scales(const LdsMap &L, int c, int ht) {
+    const int row = ht >> 3, sub = ht & 7;
+    const float *lrow = reinterpret_cast<const float *>(L.raw) + (4 * 32 + row) * c;
+    float mx = 0.f;
+    for (int p4 = sub; p4 * 4 < c; p4 += 8) {
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(lrow + 4 * p4);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    mx = fmaxf(mx, __shfl_xor(mx, 4));
+    if (sub == 0) {
+        const int sh = rtk_pack_shift(mx);
+        L.up5[row] = ldexpf(1.0f, sh);
+        L.uso5[row] = ldexpf(1.0f, -sh);
+    }
+}
+
+// Prologue of all four helper waves: query tile 0 (256 threads, requested first: its L2 round trip runs beside the
+// raw set's loads) -> buffer 0 and row-factor slot 0, and their share of the raw set -> LDS.
+template <int KS>
+__device__ __forceinline__ void h_prologue(const Geo &geo, const unsigned char *__restrict__ q_packed,
+                                           const float *__restrict__ O, const LdsMap &L, int gb, int n_g, int t) {
+    constexpr int TILE_BYTES = tile_bytes<KS>();
+    constexpr int CHUNKS = TILE_BYTES / 16;
+    constexpr int NLD = (CHUNKS + 255) / 256;
+    const int ht = t & 255;
+    u32x4 sreg[NLD];
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(q_packed);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ch = i * 256 + ht;
+        if (i + 1 < NLD || ch < CHUNKS) sreg[i] = src[ch];
+    }
+    load_raw<KS>(O, geo.N, geo.c, gb, n_g, L.raw, t);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(L.stg0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ch = i * 256 + ht;
+        if (i + 1 < NLD || ch < CHUNKS) dst[ch] = sreg[i];
+    }
+    if (ht < RTK_PACK_HDR / 16) reinterpret_cast<u32x4 *>(L.hdr)[ht] = sreg[0];
+}
+
+// "S" role: store wave SW (0, 1, 2).  The stores of a tile-step come in twenty UNITS of four row-segment stores:
+// unit u < 16 = rows 8q + 4h + {0..3} (q = u & 3) of own group u >> 2 (one 16-B read of M wave u >> 2's exchange
+// slot, tile i-2); unit 16 + b = the same rows (q = b) of the fifth group (four partial accumulators + the row
+// factors, tile i-1).  Wave SW takes the units u = SW, SW + 3, ...: 28 / 28 / 24 stores.
+template <int KS, int SIGMOID, int SW>
+__device__ __forceinline__ void s_role(const Geo &geo, const unsigned char *__restrict__ q_packed,
+                                       const float *__restrict__ O, float *__restrict__ out,
+                                       const LdsMap &L, int lane, int t, int nts, int tune) {
+    constexpr int NU = (20 - SW + 2) / 3;        // units of this wave
+    const int r = lane & 31, h = lane >> 5, c = geo.c, N = geo.N, B = geo.B, ht = t & 255;
+    const int64_t ld_out = geo.ld_out;
+    const unsigned ld4 = (unsigned)(ld_out * 4);
+    const int cnt = geo.n_mt;
+    const bool tl_on = SW == 0 && lane == 0;
+    int tl_n = 0;
+    for (int u = blockIdx.x; u < geo.U; u += gridDim.x) {
+        int gb, n_g;
+        geo.set(u, gb, n_g);
+        RTK_CG_TL(1, 1);
+        h_prologue<KS>(geo, q_packed, O, L, gb, n_g, t);
+        RTK_CG_TL(1, 2);
+        __syncthreads();                             // S1
+        RTK_CG_TL(1, 3);
+        const bool five = n_g == NG;
+        if (five) fifth_row_scales(L, c, ht);
+        __syncthreads();                             // S1b
+        __syncthreads();                             // S2
+        RTK_CG_TL(1, 4);
+        // byte offset of (row 4h, this lane's column of group g) in a tile's 32 output rows; past-the-end columns and
+        // groups the set does not have get an offset the buffer range check drops
+        const unsigned row4h = (unsigned)(4 * h * ld_out * 4);
+        unsigned colb[5];
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            const int j = (gb + g) * 32 + r;
+            colb[g] = (g < n_g && j < N) ? row4h + (unsigned)j * 4u : 0x80000000u;
+        }
+        float k5 = five ? L.uso5[r] : 0.f;
+        if (SIGMOID == 2) k5 *= -1.4426950408889634f;
+        for (int i = 0; i < cnt + 2; ++i) {
+            // Everything this wave reads from LDS in an iteration is requested in one batch (one LDS round trip: a
+            // few hundred cycles under the M waves' fragment reads), then the stores go out back to back -- the
+            // score stores are the resource that paces a tile-step (84 MB at the chip's write rate are ~1.8k cycles
+            // of each), so they start right behind the barrier and drain under the rest of the iteration.
+            const bool st_own = i >= 2, st5 = five && i >= 1 && i <= cnt;
+            f32x4 z[NU], p1[2], p2[2], p3[2], rf[2];
+            const f32x4 *ex = reinterpret_cast<const f32x4 *>(L.exo + (i & 1) * EX_BYTES) + lane;
+            const f32x4 *pr = reinterpret_cast<const f32x4 *>(L.exp5 + ((i - 1) & 1) * EX_BYTES) + lane;
+            const unsigned char *rp = L.hdr + ((i + 2) % 3) * 128 + 4 * h * 4;
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int uu = SW + 3 * k;
+                if (uu < 16) {
+                    if (st_own) z[k] = ex[(uu >> 2) * 256 + (uu & 3) * 64];
+                } else if (st5) {
+                    const int b = uu - 16, kk = k - (NU - (SW == 2 ? 1 : (SW == 1 ? 2 : 1)));   // index among this wave's fifth units
+                    z[k] = pr[b * 64];
+                    p1[kk] = pr[256 + b * 64];
+                    p2[kk] = pr[512 + b * 64];
+                    p3[kk] = pr[768 + b * 64];
+                    rf[kk] = *reinterpret_cast<const f32x4 *>(rp + b * 32);
+                }
+            }
+            RTK_CG_TL(1, 11);
+            const __amdgpu_buffer_rsrc_t rs_own = __builtin_amdgcn_make_buffer_rsrc(
+                out + (int64_t)(i - 2) * 32 * ld_out, 0, (unsigned)(min(32, B - (i - 2) * 32) * ld_out * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs5 = __builtin_amdgcn_make_buffer_rsrc(
+                out + (int64_t)(i - 1) * 32 * ld_out, 0, (unsigned)(min(32, B - (i - 1) * 32) * ld_out * 4), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                const int uu = SW + 3 * k;
+                float p[4];
+                if (uu < 16) {
+                    if (!st_own) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) p[q] = (SIGMOID == 1) ? rtk_sigmoid(z[k][q]) : z[k][q];
+                    const unsigned voff = colb[uu >> 2] + (unsigned)(uu & 3) * 8u * ld4;
+                    if (tune & 16) asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));   // (ablation: no score stores)
+                    else if (nts) store_five<2>(p, rs_own, voff, ld4);
+                    else store_five<0>(p, rs_own, voff, ld4);
+                } else {
+                    if (!st5) continue;
+                    const int b = uu - 16, kk = k - (NU - (SW == 2 ? 1 : (SW == 1 ? 2 : 1)));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float zz = (((z[k][q] + p1[kk][q]) + p2[kk][q]) + p3[kk][q]) * rf[kk][q] * k5;
+                        p[q] = SIGMOID == 2 ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zz))
+                                            : (SIGMOID == 1 ? rtk_sigmoid(zz) : zz);
+                    }
+                    const unsigned voff = colb[4] + (unsigned)b * 8u * ld4;
+                    if (tune & 16) asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+                    else if (nts) store_five<2>(p, rs5, voff, ld4);
+                    else store_five<0>(p, rs5, voff, ld4);
+                }
+            }
+            RTK_CG_TL(1, 6);
+            __syncthreads();
+            RTK_CG_TL(1, 5);
+        }
+    }
+}
+
+// "L" role: the load wave
+template <int KS>
+__device__ __forceinline__ void l_role(const Geo &geo, const unsigned char *__restrict__ q_packed,
+                                       const float *__restrict__ O, const LdsMap &L, int lane, int t, int tune) {
+    constexpr int TILE_BYTES = tile_bytes<KS>();
+    constexpr int CHUNKS = TILE_BYTES / 16;
+    constexpr int NLD = (CHUNKS + 63) / 64;     // staging 16-B chunks per lane
+    const int c = geo.c, ht = t & 255;
+    const int cnt = geo.n_mt;
+    u32x4 sreg[NLD];
+    // (through a buffer descriptor: ONE address register, the piece and tile offsets are scalar; a piece past the
+    // last tile reads as zero and is never written to LDS)
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(q_packed), 0, (unsigned)(cnt * TILE_BYTES), 0x00020000);
+    auto stage_load = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsq, (unsigned)lane * 16u, mt * TILE_BYTES + i * 1024, 0);
+    };
+    // tile mt -> buffer mt & 1; its header (32 row factors) also into slot mt % 3 of the ring that outlives the
+    // buffer (the M waves' logistic pieces and the fifth group read it two iterations later)
+    auto stage_store = [&](int mt) {
+        u32x4 *dst = reinterpret_cast<u32x4 *>((mt & 1) ? L.stg1 : L.stg0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ch = i * 64 + lane;
+            if (i + 1 < NLD || ch < CHUNKS) dst[ch] = sreg[i];
+        }
+        if (lane < RTK_PACK_HDR / 16) reinterpret_cast<u32x4 *>(L.hdr + (mt % 3) * 128)[lane] = sreg[0];
+    };
+    for (int u = blockIdx.x; u < geo.U; u += gridDim.x) {
+        int gb, n_g;
+        geo.set(u, gb, n_g);
+        h_prologue<KS>(geo, q_packed, O, L, gb, n_g, t);
+        if (cnt > 1 && !(tune & 32)) stage_load(1);  // in flight across the prologue's barriers
+        __syncthreads();                             // S1
+        if (n_g == NG) fifth_row_scales(L, c, ht);
+        __syncthreads();                             // S1b
+        __syncthreads();                             // S2
+        for (int i = 0; i < cnt + 2; ++i) {
+            // tile i+1 was requested an iteration ago (tile 1: in the prologue); buffer (i+1) & 1 held tile i-1, which
+            // the M waves left at the last barrier.  Tile i+2 is requested right behind the write, into the same
+            // registers: its L2 round trip has a whole tile-step.
+            if (i + 1 < cnt && !(tune & 32)) stage_store(i + 1);
+            if (i + 2 < cnt && !(tune & 32)) stage_load(i + 2);
+            __syncthreads();
+        }
+    }
+}
+
+template <int KS, int SIGMOID>
+__global__ __launch_bounds__(512, 2) void score_cg_kernel(
+    const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
+    float *__restrict__ out, int64_t ld_out, int U, int nts, int tune) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    LdsMap L;
+    L.init<KS>(lds);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    Geo geo;
+    geo.B = B; geo.N = N; geo.c = c; geo.U = U; geo.n_mt = (B + 31) / 32; geo.ld_out = ld_out;
+    // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler); one instantiation
+    // of the M role per wave: the fifth group's k-range, and with it the gap schedule, is static
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    // (A/B knob, RTK_CG_TUNE: bits 0-1 = static priority of the helper waves, bits 2-3 = of the M waves)
+    {
+        const int pr = __builtin_amdgcn_readfirstlane(uwave >= 4 ? (tune & 3) : ((tune >> 2) & 3));
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    if (uwave == 0) m_role<KS, 0, SIGMOID>(geo, O, L, lane, t);
+    else if (uwave == 1) m_role<KS, 1, SIGMOID>(geo, O, L, lane, t);
+    else if (uwave == 2) m_role<KS, 2, SIGMOID>(geo, O, L, lane, t);
+    else if (uwave == 3) m_role<KS, 3, SIGMOID>(geo, O, L, lane, t);
+    else if (uwave == 4) s_role<KS, SIGMOID, 0>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
+    else if (uwave == 5) s_role<KS, SIGMOID, 1>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
+    else if (uwave == 6) s_role<KS, SIGMOID, 2>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
+    else l_role<KS>(geo, q_packed, O, L, lane, t, __builtin_amdgcn_readfirstlane(tune));
+}
+
+}  // namespace rtk_cg

@@ -75,15 +75,23 @@ int launch_loss(const unsigned char *qp, int B, const float *O, int N, int c, fl
 int rtk_score_ws_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                         int sg, bool o_vec, hipStream_t st);
 
-// Default: the persistent wave-specialised kernel (ws), then the two-workgroups-per-CU kernel (v3)
-// for the shapes ws does not cover.  RTK_SCORE_KERNEL=v3 forces v3 (A/B comparisons).  (The
-// two-tiles-per-barrier variant "ws2" was measured slower, 53.9 vs 48.5 us at the WN18RR shape, and
-// lives in tools/ablate/ only.)
+int rtk_score_cg_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
+                        int sg, bool o_vec, bool force, hipStream_t st);
+
+// Default: the column-group kernel (cg) where its schedule fills the chip (rtk_score_cg.hip), else the
+// persistent wave-specialised kernel (ws), then the two-workgroups-per-CU kernel (v3) for the shapes
+// neither covers.  RTK_SCORE_KERNEL=v3 forces v3, =ws skips cg, =cg runs cg on every shape it can
+// (c <= 208) -- A/B comparisons and tests.  (The two-tiles-per-barrier variant "ws2" was measured
+// slower, 53.9 vs 48.5 us at the WN18RR shape, and lives in tools/ablate/ only.)
+// 0 = v3 only, 1 = ws then v3, 2 = cg (by shape) then ws then v3, 3 = cg (forced) then ws then v3
 static int kernel_choice() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("RTK_SCORE_KERNEL");
-        v = (e && e[0] == 'v' && e[1] == '3') ? 0 : 1;
+        if (e && e[0] == 'v' && e[1] == '3') v = 0;
+        else if (e && e[0] == 'w' && e[1] == 's') v = 1;
+        else if (e && e[0] == 'c' && e[1] == 'g') v = 3;
+        else v = 2;
     }
     return v;
 }
@@ -108,7 +116,15 @@ extern "C" int rtk_score_packed_f32(const void *q_packed, int64_t batch, int c, 
     const bool o_vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(O) & 15) == 0);
     const int B = (int)batch, N = (int)n_local;
     const unsigned char *qp = (const unsigned char *)q_packed;
-    if (kernel_choice() >= 1) {
+    const unsigned hint = flags & RTK_SCORE_KERNEL_MASK;
+    const int choice = hint == RTK_SCORE_KERNEL_CG ? 3 : hint == RTK_SCORE_KERNEL_WS ? 1 : hint == RTK_SCORE_KERNEL_V3 ? 0
+                                                                                                        : kernel_choice();
+    if (choice >= 2) {
+        const int took = rtk_score_cg_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, choice == 3, st);
+        if (took < 0) return took;
+        if (took) return rtk_check_launch("rtk_score_packed_f32");
+    }
+    if (choice >= 1) {
         const int took = rtk_score_ws_launch(qp, B, O, N, c, out, ld_out, sg, o_vec, st);
         if (took < 0) return took;
         if (took) return rtk_check_launch("rtk_score_packed_f32");
