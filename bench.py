@@ -65,7 +65,7 @@ def cpu_baseline(gen, n_ent, n_rel, B, rank, pool, budget_s=15.0):
     from oracle import score_oracle as orc
     core, R, S, O = [torch.from_numpy(x) for x in gen.make_params(n_ent, n_rel, rank, 322)]
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cands = sorted({t for t in (avail, 64, 32, 16, 8) if t <= avail})
+    cands = sorted({t for t in (avail, 64, 32, 16, 8, 1) if t <= avail})       # (1 thread: SURVEY.md section 8d asks for both)
     best = None
     tried = []
     with torch.no_grad():
@@ -84,11 +84,66 @@ def cpu_baseline(gen, n_ent, n_rel, B, rank, pool, budget_s=15.0):
             if best is None or n * B / dt > best[1]:
                 best = (th, n * B / dt, n, dt)
     th, qps, n, dt = best
+    one = [q for t, q in tried if t == 1]
     return {"value": qps, "unit": "queries/s", "cores": th, "kind": "port",
+            "one_thread_value": one[0] if one else None,
             "sample": f"{n} batches of {B} queries ({dt:.1f} s) of the same workload, torch {torch.__version__} CPU fp32, "
                       f"best of thread counts {[(a, round(b)) for a, b in tried]} ({avail} hardware threads visible); "
                       f"oracle/score_oracle.py::score_ref; the CPU leg runs all five ops for every batch (no table caching): "
                       f"the like-for-like GPU figure is per_batch_ms_per_step"}
+
+
+def surface_timings(rt, core, R, S, O, sym, pool, n_ent, n_rel, trank, B, workload, dev, n_calls=400):
+    """Wall time per call of the reference-protocol surface on the bench operands: `model(h, r)(T)` in eval mode under
+    no_grad (relation tables cached by the model, like the reference's evaluate() which scores every batch with one
+    extract_tensor(model)) with the out-of-range-id check deferred to the caller's sync point (what evaluate() and the
+    training driver do) and with the default per-call check (one stream synchronisation per call); and, for the
+    WN18RR workload, rt.evaluate() over the real test split."""
+    out = {}
+    Model = rt.SymmetricR_TuckER if sym else rt.AsymmetricR_TuckER
+    model = Model((n_ent, n_rel), tuple(trank))
+    with torch.no_grad():
+        model.core.data = core
+        model.R.weight.data = R
+        if sym:
+            model.E.weight.data = S
+        else:
+            model.S.weight.data, model.O.weight.data = S, O
+    model.eval()
+    T = (rt.SFTucker(model.core.data, [model.R.weight], num_shared_factors=2, shared_factor=model.E.weight) if sym
+         else rt.Tucker(model.core.data, [model.R.weight, model.S.weight, model.O.weight]))
+    with torch.no_grad():
+        for mode, key in (("deferred", "closure_ms_per_step"), ("strict", "closure_strict_check_ms_per_step")):
+            with rt.index_check(mode):
+                for i in range(30):
+                    model(*pool[i % len(pool)])(T)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for i in range(n_calls):
+                    model(*pool[i % len(pool)])(T)
+                torch.cuda.synchronize(dev)
+                out[key] = (time.perf_counter() - t0) / n_calls * 1e3
+        rt.check_device_errors(dev)
+    data_dir = os.path.join(ROOT, "data", "WN18RR")
+    if workload.startswith("wn18rr") and os.path.exists(os.path.join(data_dir, "test.txt")):
+        from r_tucker_amd.data import Data, KG_dataset
+        data = Data(data_dir + "/", reverse=True)
+        if len(data.entities) == n_ent and len(data.relations) == n_rel:
+            test_set = KG_dataset(data, data.test_data, test_set=True)
+            for _ in range(3):
+                rt.evaluate(model, test_set, batch_size=B)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            n_pass = 10
+            for _ in range(n_pass):
+                rt.evaluate(model, test_set, batch_size=B)
+            torch.cuda.synchronize(dev)
+            per_pass = (time.perf_counter() - t0) / n_pass * 1e3
+            nb = -(-len(test_set) // B)
+            out["evaluate_ms_per_pass"] = per_pass
+            out["evaluate_ms_per_batch"] = per_pass / nb
+            out["evaluate_batches_per_pass"] = nb
+    return out
 
 
 def launch_children(argv, n):
@@ -390,6 +445,12 @@ def main():
                 e1.record(stream)
                 barrier()
             extras["score_kernel_back_to_back_ms"] = e0.elapsed_time(e1) / 64
+        # the drop-in surface: the eval-mode closure `model(h, r)(T)` of the reference's protocol on the
+        # same operands and batches, and `evaluate()` over the WN18RR test split (13 batches of 512; train.py:94-125)
+        try:
+            extras.update(surface_timings(rt, core, R, S, O, sym, pool, n_ent, n_rel, trank, B, args.workload, dev))
+        except Exception as e:       # the headline line must survive a failure of this extra leg
+            extras["surface_error"] = repr(e)
         if not bf16 and c <= 512:
             ex = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(12)]
             for e2 in ex:

@@ -306,6 +306,10 @@ int rtk_filtered_rank_f32(const float *P, int64_t batch, int64_t n_ent, int64_t 
  * totals train.py:118-121 keeps per evaluation, without a device -> host copy per batch.
  */
 int rtk_rank_metrics_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double *acc5, void *stream);
+/* The same with every BCE row sum multiplied by bce_scale first: the reference averages the per-batch MEAN losses
+ * (train.py:113,125), i.e. bce_scale = 1 / (batch * n_ent), without a pass over the row sums in between. */
+int rtk_rank_metrics_scaled_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double bce_scale,
+                                double *acc5, void *stream);
 
 /*
  * Training forward with the loss fused into the score kernel's epilogue (reference train.py:79,136:

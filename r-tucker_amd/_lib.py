@@ -59,6 +59,7 @@ SIGNATURES = {
     "rtk_bce_rows_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, _p]),
     "rtk_bce_grad_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, C.c_float, _p]),
     "rtk_rank_metrics_f64": (_i, [_p, _p, _i64, _p, _p]),
+    "rtk_rank_metrics_scaled_f64": (_i, [_p, _p, _i64, C.c_double, _p, _p]),
     "rtk_score_bce_partials": (_i, []),
     "rtk_score_packed_bce_f32": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, C.c_float, _p, _p]),
     "rtk_bce_patch_pos_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_float, _p, _p, _i, _p, _p]),

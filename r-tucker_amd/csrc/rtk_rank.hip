@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void target_scores_kernel(const float *__restr
 // (src/utils/metrics.py:4-22 returns exactly these batch sums; train.py:118-121 adds them up)
 __global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__restrict__ ranks,
                                                            const double *__restrict__ bce_rows, int B,
-                                                           double *__restrict__ acc) {
+                                                           double *__restrict__ acc, double bce_scale) {
     __shared__ double s[4][5];
     const int t = threadIdx.x;
     double v[5] = {0, 0, 0, 0, 0};
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__rest
         v[1] += rk <= 1;
         v[2] += rk <= 3;
         v[3] += rk <= 10;
-        if (bce_rows) v[4] += bce_rows[d];
+        if (bce_rows) v[4] += bce_rows[d] * bce_scale;
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -133,8 +133,15 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__rest
 extern "C" int rtk_rank_metrics_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double *acc5,
                                     void *stream) {
     RTK_REQUIRE(ranks && acc5 && batch > 0 && batch < (1ll << 31), RTK_ERR_BAD_ARG, "rtk_rank_metrics_f64: bad argument");
-    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ranks, bce_rows, (int)batch, acc5);
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ranks, bce_rows, (int)batch, acc5, 1.0);
     return rtk_check_launch("rtk_rank_metrics_f64");
+}
+
+extern "C" int rtk_rank_metrics_scaled_f64(const int32_t *ranks, const double *bce_rows, int64_t batch, double bce_scale,
+                                           double *acc5, void *stream) {
+    RTK_REQUIRE(ranks && acc5 && batch > 0 && batch < (1ll << 31), RTK_ERR_BAD_ARG, "rtk_rank_metrics_scaled_f64: bad argument");
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ranks, bce_rows, (int)batch, acc5, bce_scale);
+    return rtk_check_launch("rtk_rank_metrics_scaled_f64");
 }
 
 extern "C" int rtk_target_scores_f32(const float *P, int64_t batch, int64_t n_local, int64_t ld, int64_t col0,

@@ -55,8 +55,18 @@ static __device__ unsigned long long g_cg_tl[256 * 2 * 64];
             ++tl_n;                                                                                             \
         }                                                                                                       \
     } while (0)
+// (the constant 100 MHz counter beside the shader clock: the in-kernel clock is their ratio)
+#define RTK_CG_TLR(role, code)                                                                                  \
+    do {                                                                                                        \
+        if (tl_on && tl_n < 64) {                                                                               \
+            g_cg_tl[(blockIdx.x * 2 + (role)) * 64 + tl_n] =                                                    \
+                ((unsigned long long)(code) << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull); \
+            ++tl_n;                                                                                             \
+        }                                                                                                       \
+    } while (0)
 #else
 #define RTK_CG_TL(role, code) do { (void)tl_on; (void)tl_n; } while (0)
+#define RTK_CG_TLR(role, code) do { (void)tl_on; (void)tl_n; } while (0)
 #endif
 
 constexpr int NG = 5;                       // groups per set (4 in registers + 1 split along K)
@@ -128,23 +138,30 @@ __device__ __forceinline__ float convert_row(const unsigned char *raw, int row, 
     const float *lrow = reinterpret_cast<const float *>(raw) + row_off;
     float mx = 0.f;
     if constexpr (K1 - K0 == KS) {
-        // whole row: read once, keep in registers for the maximum and the conversion
+        // whole row: read once, keep in registers for the maximum and the conversion.  KS = ceil(c / 16), so only the
+        // LAST k-step can reach past column c: the others need no mask (the masks were a third of this pass).
         f32x4 rw[2 * KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = 16 * ks + h8;                  // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
-            rw[2 * ks] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
-            rw[2 * ks + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
+            if (ks + 1 < KS) {
+                rw[2 * ks] = *reinterpret_cast<const f32x4 *>(lrow + k);
+                rw[2 * ks + 1] = *reinterpret_cast<const f32x4 *>(lrow + k + 4);
+            } else {
+                rw[2 * ks] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
+                rw[2 * ks + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!(k + 4 <= c)) rw[2 * ks][q] = 0.f;
+                    if (!(k + 8 <= c)) rw[2 * ks + 1][q] = 0.f;
+                }
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int k = 16 * ks + h8;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!(k + 4 <= c)) rw[2 * ks][q] = 0.f;
-                if (!(k + 8 <= c)) rw[2 * ks + 1][q] = 0.f;
-                mx = fmaxf(mx, fmaxf(fabsf(rw[2 * ks][q]), fabsf(rw[2 * ks + 1][q])));
-            }
+            for (int q = 0; q < 4; ++q)      // one v_max3_f32 with |.| modifiers per pair
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mx) : "v"(rw[2 * ks][q]), "v"(rw[2 * ks + 1][q]));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const int sh = rtk_pack_shift(mx);
@@ -179,15 +196,17 @@ __device__ __forceinline__ void convert_range(const unsigned char *raw, int row,
 #pragma unroll
     for (int ks = K0; ks < K1; ++ks) {
         const int k = 16 * ks + h8;
-        rw[2 * (ks - K0)] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
-        rw[2 * (ks - K0) + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
+        const bool last = ks + 1 == KS;              // (only the last k-step can reach past column c)
+        rw[2 * (ks - K0)] = *reinterpret_cast<const f32x4 *>(lrow + ((!last || k + 4 <= c) ? k : 0));
+        rw[2 * (ks - K0) + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((!last || k + 8 <= c) ? k + 4 : 0));
     }
 #pragma unroll
     for (int ks = K0; ks < K1; ++ks) {
         const int k = 16 * ks + h8;
+        const bool last = ks + 1 == KS;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float y0 = (k + 4 <= c) ? rw[2 * (ks - K0)][q] * up : 0.f, y1 = (k + 8 <= c) ? rw[2 * (ks - K0) + 1][q] * up : 0.f;
+            const float y0 = (!last || k + 4 <= c) ? rw[2 * (ks - K0)][q] * up : 0.f, y1 = (!last || k + 8 <= c) ? rw[2 * (ks - K0) + 1][q] * up : 0.f;
             const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
             Bh[ks - K0][q] = h0;
             Bh[ks - K0][4 + q] = h1;
@@ -221,7 +240,10 @@ struct LdsMap {
 template <int KS, int W4, int SIGMOID, bool EXTRA>
 __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, const f16x8 (&Bh)[KS], const f16x8 (&Bl)[KS],
                                         const f16x8 *Sh, const f16x8 *Sl, float us_o, bool tl_on, int &tl_n) {
-    constexpr int PF = KS < 3 ? KS : 3;         // A-fragment prefetch distance (k-steps)
+#ifndef RTK_CG_PF
+#define RTK_CG_PF 3
+#endif
+    constexpr int PF = KS < RTK_CG_PF ? KS : RTK_CG_PF;   // A-fragment prefetch distance (k-steps)
     constexpr int S0 = s_begin(KS, W4), S1 = s_end(KS, W4), NS = EXTRA ? S1 - S0 : 0;
     constexpr int NGAP = 3 * KS + 3 * NS;       // MFMAs (= gaps) of one chain
     // the partial accumulator is complete after the last shared MFMA (gap 3*S1 + 3*NS - 1); its four 16-B
@@ -368,6 +390,7 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
     const int r = lane & 31, h = lane >> 5, c = geo.c;
     const bool tl_on = W4 == 0 && lane == 0;
     int tl_n = 0;
+    RTK_CG_TLR(0, 12);
     for (int u = blockIdx.x; u < geo.U; u += gridDim.x) {
         int gb, n_g;
         geo.set(u, gb, n_g);
@@ -393,6 +416,7 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
             m_sweep<KS, W4, SIGMOID, false>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, tl_on, tl_n);
         }
     }
+    RTK_CG_TLR(0, 13);
 }
 
 // ---- H role ------------------------------------------------------------------------------------------------

@@ -169,7 +169,11 @@ __global__ __launch_bounds__(256, MINW) void score_split_kernel(
                 if (LOSS) {
                     const float term = t0 * split_clog(pv) + (1.0f - t0) * split_clog(1.0f - pv);
                     if (j < N && row + 4 * h < ep_rows) loss_tile += term;
-                    pv = (pv == 1.0f) ? 0.0f : ((pv == 0.0f) ? -0.0f : pv - t0);   // (the sign of the zero tells the patch kernel which)
+                    // (the sign of the zero tells the patch kernel which; a score that merely EQUALS t0 -- p = eps / N is an
+                    // ordinary fp32 value, e.g. 2.4e-6 at WN18RR: a positive with logit -12.9 -- must not read as saturated:
+                    // it is stored as the smallest denormal, 1.4e-45 away from its exact logit gradient of zero)
+                    const float xv = pv - t0;
+                    pv = (pv == 1.0f) ? 0.0f : ((pv == 0.0f) ? -0.0f : (xv == 0.0f ? __builtin_bit_cast(float, 1u) : xv));
                 }
                 if (off(4)) {
                     if (pv == 12345.678f) out[0] = pv;

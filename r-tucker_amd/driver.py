@@ -84,14 +84,54 @@ def batch_loss_fn(model, subject_idx, relation_idx, flt, item_ids, label_smoothi
     return RegularisedLoss(bce, regularization_coeff)
 
 
+class EagerTrainStep:
+    """One batch of ``train.py:76-85`` -- ``optimizer.fit(loss_fn, x_k); optimizer.step()`` -- on the ids handed to
+    ``run``; the loss and gradient-norm sums that ``train_one_epoch`` reports are accumulated on the device (one
+    synchronisation per epoch instead of the reference's two ``.item()`` per batch in its progress bar)."""
+
+    def __init__(self, model, optimizer, flt, batch_size: int, label_smoothing: float, extract_tensor, batch_loss_fn):
+        self.model, self.opt, self.flt = model, optimizer, flt
+        self.B = int(batch_size)
+        self.ls = float(label_smoothing)
+        self._extract, self._loss_fn = extract_tensor, batch_loss_fn
+        dev = flt.device
+        self.dev = dev
+        self.reg = torch.zeros((), dtype=torch.float32, device=dev)
+        self.loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        self.gnorm_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        self.replays = 0
+
+    def begin_epoch(self, regularization_coeff: float):
+        self.reg.fill_(float(regularization_coeff))
+        self.opt.refresh_lr()
+        self.loss_sum.zero_()
+        self.gnorm_sum.zero_()
+
+    def run(self, ids: torch.Tensor):
+        f = self.flt.features[ids]
+        loss_fn = self._loss_fn(self.model, f[:, 0].contiguous(), f[:, 1].contiguous(), self.flt, ids, self.ls, self.reg)
+        x_k = self._extract(self.model)
+        gn = self.opt.fit(loss_fn, x_k)
+        self.opt.step()
+        self.loss_sum += self.opt.loss.detach().to(torch.float32)
+        self.gnorm_sum += gn.detach().to(torch.float32)
+
+    def totals(self):
+        """(sum of losses, sum of gradient norms) over the steps since ``begin_epoch`` -- one synchronisation."""
+        return float(self.loss_sum), float(self.gnorm_sum)
+
+
+# what builds the per-batch step object (``begin_epoch`` / ``run(ids)`` / ``totals``); the HIP-graph replay of the step
+# is an experiment outside the package (tools/graphstep.py: ``graphstep.install()`` swaps it in)
+TRAIN_STEP_FACTORY = EagerTrainStep
+
+
 def _captured_step(model, optimizer, train_flt, batch_size, label_smoothing):
-    """The per-batch step as a replayable HIP graph (``graphstep.CapturedTrainStep``), kept on the optimizer so
-    that later epochs reuse the capture."""
-    from .graphstep import CapturedTrainStep
-    key = (id(model), id(train_flt), int(batch_size), float(label_smoothing))
+    """The per-batch step object, kept on the optimizer so that later epochs reuse it (and its device buffers)."""
+    key = (id(model), id(train_flt), int(batch_size), float(label_smoothing), TRAIN_STEP_FACTORY)
     cur = getattr(optimizer, "_rtk_captured", None)
     if cur is None or cur[0] != key:
-        cur = (key, CapturedTrainStep(model, optimizer, train_flt, batch_size, label_smoothing, extract_tensor, batch_loss_fn))
+        cur = (key, TRAIN_STEP_FACTORY(model, optimizer, train_flt, batch_size, label_smoothing, extract_tensor, batch_loss_fn))
         optimizer._rtk_captured = cur
     return cur[1]
 
@@ -99,9 +139,9 @@ def _captured_step(model, optimizer, train_flt, batch_size, label_smoothing):
 def train_one_epoch(model, optimizer, train_flt: DeviceFilter, batch_size, label_smoothing, regularization_coeff=1e-4,
                     max_batches=None, log=None):
     """``train.py:69-91``: one pass over the (s, r) pairs of the train split; returns the mean loss and mean
-    Riemannian gradient norm over the batches.  The batch step (``fit`` + ``step``) runs from a HIP graph after
-    its first two eager executions; loss and gradient norm are summed on the device (one synchronisation per
-    epoch instead of the reference's two ``.item()`` per batch in its progress bar)."""
+    Riemannian gradient norm over the batches.  The batch step (``fit`` + ``step``) runs eagerly (``EagerTrainStep``);
+    loss and gradient norm are summed on the device (one synchronisation per epoch instead of the reference's two
+    ``.item()`` per batch in its progress bar)."""
     model.train()
     dev = train_flt.device
     n = train_flt.features.shape[0]

@@ -34,10 +34,41 @@ class DeviceFilter:
         obj = (key % m).astype(np.int64)
         self.pair_ptr = torch.as_tensor(ptr, device=self.device)
         self.pair_obj = torch.as_tensor(obj, device=self.device)
-        f = dataset.features
-        slots = np.fromiter((dataset._pair_slot[(int(s), int(r))] for s, r in f[:, :2]), dtype=np.int64, count=len(f))
+        f = np.asarray(dataset.features, dtype=np.int64)
+        # pair slot of every item, vectorised (a Python loop over the items cost more than the evaluation pass itself):
+        # the pairs' (s, r) keys sorted once, the items' keys located by binary search
+        if hasattr(dataset, "_pairs"):
+            pairs = np.asarray(dataset._pairs, dtype=np.int64).reshape(-1, 2)
+        else:                                    # (a dataset that only keeps the (s, r) -> slot dictionary)
+            pairs = np.zeros((len(dataset._pair_slot), 2), dtype=np.int64)
+            for (s_, r_), i in dataset._pair_slot.items():
+                pairs[i] = (s_, r_)
+        nr = int(max(pairs[:, 1].max() if len(pairs) else 0, f[:, 1].max() if len(f) else 0)) + 1
+        pk = pairs[:, 0] * nr + pairs[:, 1]
+        order = np.argsort(pk, kind="stable")
+        ik = f[:, 0] * nr + f[:, 1]
+        pos = np.searchsorted(pk[order], ik)
+        if len(f) and (pos.max(initial=0) >= len(pk) or not np.array_equal(pk[order][np.minimum(pos, len(pk) - 1)], ik)):
+            raise KeyError("an item's (subject, relation) pair is not among the dataset's pairs")
+        slots = order[pos] if len(f) else np.zeros(0, np.int64)
         self.slot_of_item = torch.as_tensor(slots, device=self.device)
-        self.features = torch.as_tensor(np.asarray(f, dtype=np.int64), device=self.device)
+        self.features = torch.as_tensor(f, device=self.device)
+        # contiguous columns: the evaluation loop hands the kernels pointer offsets into them
+        self.subj = self.features[:, 0].contiguous()
+        self.rel = self.features[:, 1].contiguous()
+        self.obj = self.features[:, 2].contiguous() if f.shape[1] > 2 else None
+        self._plans = {}
+
+    @classmethod
+    def of(cls, dataset, device):
+        """The filter of ``dataset`` on ``device``, built once per dataset object (``evaluate()`` runs twice per epoch)."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        cache = dataset.__dict__.setdefault("_device_filters", {})
+        if device not in cache:
+            cache[device] = cls(dataset, device)
+        return cache[device]
 
 
 def filtered_ranks(P: torch.Tensor, obj_idx: torch.Tensor, flt: DeviceFilter = None, item_ids: torch.Tensor = None,
@@ -119,14 +150,94 @@ def metrics_from_ranks(ranks: torch.Tensor):
             "hits@10": (ranks <= 10).sum()}
 
 
+class _EvalPlan:
+    """Buffers of one evaluation pass for fixed (batch size, entity count, operand dtype): the score matrix of ONE
+    batch (every batch is consumed by the ranking kernel on the same stream before the next one overwrites it),
+    ranks, BCE row sums, packed query planes, running sums."""
+
+    def __init__(self, B, N, c, n_rel, dtype, device):
+        from .ops import alloc_scores
+        lib = _lib.load()
+        bf16 = dtype == torch.bfloat16
+        self.dcode = _lib.RTK_BF16 if bf16 else _lib.RTK_F32
+        self.P = alloc_scores(B, N, device)
+        self.ld = self.P.stride(0) if B > 1 else N
+        self.ranks = torch.empty(B, dtype=torch.int32, device=device)
+        self.bce = torch.empty(B, dtype=torch.float64, device=device)
+        self.acc = torch.zeros(5, dtype=torch.float64, device=device)
+        self.qp = torch.empty(lib.rtk_packed_query_bytes(self.dcode, B, c), dtype=torch.uint8, device=device)
+        self.ws_bytes = lib.rtk_from_tables_workspace_bytes(B, n_rel)
+
+
 @torch.no_grad()
 def evaluate(model, dataset, batch_size=512, device=None, flt: DeviceFilter = None):
     """The reference's ``evaluate`` loop on the device.  ``dataset``: a test-mode ``KG_dataset``.
-    Returns (metrics dict averaged over queries, mean BCE loss) like train.py:123-125."""
-    from .ops import check_device_errors, index_check
+    Returns (metrics dict averaged over queries, mean BCE loss) like train.py:123-125.
+
+    Per batch: stage 1 against the relation tables of the frozen parameters, the score kernel, the filtered-rank
+    kernel over the score matrix, the metric sums -- four calls into the C ABI on buffers that are allocated once per
+    (dataset, batch size) and reused; the filter CSR is built once per dataset object.  Out-of-range ids are reported
+    at the pass's own synchronisation point (reference: IndexError)."""
+    from . import ops
     device = torch.device(device) if device is not None else next(model.parameters()).device
-    flt = flt or DeviceFilter(dataset, device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    flt = flt or DeviceFilter.of(dataset, device)
     model.eval()          # train.py:96; also drops the relation-table cache: the tables are rebuilt once, below
+    sym = hasattr(model, "E")
+    core, R = model.core.data, model.R.weight.data
+    S = model.E.weight.data if sym else model.S.weight.data
+    O = S if sym else model.O.weight.data
+    n = len(dataset)
+    a, b, c = core.shape
+    if (b != c or core.dtype not in (torch.float32, torch.bfloat16) or c > 512 or not core.is_cuda
+            or any(t.dtype != core.dtype or t.device != core.device or not t.is_contiguous() for t in (R, S, O))):
+        return _evaluate_generic(model, dataset, batch_size, device, flt)      # (raises what the closure raises)
+    lib = _lib.load()
+    N, n_rel = O.shape[0], R.shape[0]
+    bf16 = core.dtype == torch.bfloat16
+    key = (batch_size, N, c, n_rel, core.dtype)
+    plan = flt._plans.get(key)
+    if plan is None:
+        plan = flt._plans[key] = _EvalPlan(min(batch_size, max(n, 1)), N, c, n_rel, core.dtype, device)
+    tables = model._cached_tables(core, R) if hasattr(model, "_cached_tables") else None
+    if tables is None:
+        tables = ops.relation_tables(core, R)
+    ft = lib.rtk_query_vectors_from_tables_bf16 if bf16 else lib.rtk_query_vectors_from_tables_f32
+    sp_fn = lib.rtk_score_packed_bf16 if bf16 else lib.rtk_score_packed_f32
+    sflags = _lib.RTK_SCORE_SIGMOID | (_lib.RTK_SCORE_SIGMOID_FAST if ops.DEFAULT_SIGMOID == "fast" else 0)
+    with torch.cuda.device(device):
+        sp = torch.cuda.current_stream(device).cuda_stream
+        ws = ops._workspace(device, sp, plan.ws_bytes)
+        plan.acc.zero_()
+        P, qp, ranks, bce, acc = (plan.P.data_ptr(), plan.qp.data_ptr(), plan.ranks.data_ptr(), plan.bce.data_ptr(),
+                                  plan.acc.data_ptr())
+        tp, Sp, Op, wsp, wsn = tables.data_ptr(), S.data_ptr(), O.data_ptr(), ws.data_ptr(), ws.numel()
+        hp, rp, op, slp = flt.subj.data_ptr(), flt.rel.data_ptr(), flt.obj.data_ptr(), flt.slot_of_item.data_ptr()
+        ptr, objs = flt.pair_ptr.data_ptr(), flt.pair_obj.data_ptr()
+        n_batches = 0
+        for lo in range(0, n, batch_size):
+            nb = min(batch_size, n - lo)
+            o8 = 8 * lo
+            _lib.check(ft(tp, n_rel, b, c, Sp, S.shape[0], rp + o8, hp + o8, nb, None, qp, wsp, wsn, sp),
+                       "rtk_query_vectors_from_tables")
+            _lib.check(sp_fn(qp, nb, c, Op, N, P, plan.ld, sflags, sp), "rtk_score_packed")
+            _lib.check(lib.rtk_filtered_rank_f32(P, nb, N, plan.ld, op + o8, slp + o8, ptr, objs, ranks, bce, sp),
+                       "rtk_filtered_rank_f32")
+            # the reference averages the per-batch MEAN losses (train.py:113,125)
+            _lib.check(lib.rtk_rank_metrics_scaled_f64(ranks, bce, nb, 1.0 / (nb * N), acc, sp), "rtk_rank_metrics_scaled_f64")
+            n_batches += 1
+    acc = plan.acc.cpu().tolist()
+    ops.check_device_errors(device)
+    sums = {"mrr": acc[0] / n, "hits@1": acc[1] / n, "hits@3": acc[2] / n, "hits@10": acc[3] / n}
+    return sums, acc[4] / max(n_batches, 1)
+
+
+@torch.no_grad()
+def _evaluate_generic(model, dataset, batch_size, device, flt):
+    """The same loop through the model's closure (any operand the closure accepts; shapes the fast path does not
+    cover end in the closure's own error)."""
+    from .ops import check_device_errors, index_check
     if hasattr(model, "E"):
         T = SFTucker(model.core.data, [model.R.weight], num_shared_factors=2, shared_factor=model.E.weight)
     else:

@@ -71,11 +71,35 @@ def _f32c(name, t):
 
 
 def _idx(name, t, device):
+    if isinstance(t, torch.Tensor) and t.dtype == torch.int64 and t.device == device and t.dim() == 1 and t.is_contiguous():
+        return t
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(t)
     if t.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8, torch.int8):
         raise IndexError(f"{name} must be an integer tensor, got {t.dtype}")  # torch: "tensors used as indices must be long..."
     return t.to(device=device, dtype=torch.int64).contiguous().view(-1)
+
+
+_sizes = {}      # memoised size queries of the C ABI (one ctypes call each otherwise, per scoring call)
+_packed = {}     # (device index, stream) -> packed-query-plane buffer of the no-autograd path
+
+
+def _size(fn_name, *args):
+    key = (fn_name,) + args
+    v = _sizes.get(key)
+    if v is None:
+        v = _sizes[key] = getattr(_lib.load(), fn_name)(*args)
+    return v
+
+
+def _packed_buffer(device, stream_ptr, nbytes):
+    """Packed query planes of a call that does not hand them out: written by stage 1 and read by the score kernel
+    of the same call on the same stream, so one buffer per (device, stream) serves every call (no allocation)."""
+    key = (device.index, stream_ptr)
+    b = _packed.get(key)
+    if b is None or b.numel() < nbytes:
+        b = _packed[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    return b
 
 
 def _workspace(device, stream_ptr, nbytes):
@@ -218,9 +242,9 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
                     or not tables.is_contiguous()):
                 raise RuntimeError(f"tables must be a contiguous float32 ({R.shape[0]}, {b}, {c}) tensor on {dev} "
                                    "(ops.relation_tables)")
-            need = lib.rtk_from_tables_workspace_bytes(B, R.shape[0])
+            need = _size("rtk_from_tables_workspace_bytes", B, R.shape[0])
         else:
-            need = lib.rtk_workspace_bytes(dcode, B, R.shape[0], a, b, c)
+            need = _size("rtk_workspace_bytes", dcode, B, R.shape[0], a, b, c)
         ws = _workspace(dev, sp, need)
         if bf16 and (exact or c > 512):
             raise RuntimeError("bf16 operands: only the bf16 MFMA score kernel exists (c <= 512, exact=False)")
@@ -245,7 +269,7 @@ def _forward(core, R, S, O, subject_idx, relation_idx, sigmoid, exact, want_v, s
                 qp = None
             else:
                 v = torch.empty((B, c), dtype=torch.float32, device=dev) if want_v else None
-                qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev)
+                qp = _packed_buffer(dev, sp, _size("rtk_packed_query_bytes", dcode, B, c))
             ft = lib.rtk_query_vectors_from_tables_bf16 if bf16 else lib.rtk_query_vectors_from_tables_f32
             _lib.check(ft(tables.data_ptr(), R.shape[0], b, c, S.data_ptr(), S.shape[0], r.data_ptr(), h.data_ptr(), B,
                           v.data_ptr() if v is not None else None, qp.data_ptr() if qp is not None else None,
@@ -641,6 +665,28 @@ def score_packed_into(qp, B, O, out, sigmoid=True, sigmoid_mode=None):
         _lib.check(fn(qp.data_ptr(), B, c, O.data_ptr(), N, out.data_ptr(), out.stride(0) if B > 1 else N, flags,
                       _stream_ptr(dev)), "rtk_score_packed")
     return out
+
+
+def cg_fifth_group_columns(N, c, n_cu=256):
+    """Boolean mask (N,) of the entity columns that the default fp32 score kernel computes as FOUR K-range chains added
+    in a fixed order instead of one chain -- the fifth column group of a workgroup's set in the column-group kernel
+    (csrc/rtk_score_cg.hip: chosen for one set per workgroup on a full grid, 36 000 < N <= 40 960 on 256 CUs, c <= 208,
+    c % 4 == 0).  Everywhere else (all False for other shapes) a score does not depend on how many other entities are
+    scored with it; on these columns an entity-sharded run and a single-device run differ in the last bits."""
+    import numpy as np
+    mask = np.zeros(N, dtype=bool)
+    G = -(-N // 32)
+    sets_min = -(-G // 5)
+    W = min(n_cu, sets_min)
+    P = -(-sets_min // W)
+    if c > 208 or c % 4 or not (P == 1 and W == n_cu and 10 * G >= 44 * W):
+        return mask
+    U = W * P
+    for u in range(U):
+        gb, ge = G * u // U, G * (u + 1) // U
+        if ge - gb == 5:
+            mask[(gb + 4) * 32:min(N, (gb + 5) * 32)] = True
+    return mask
 
 
 def check_device_errors(device=None):

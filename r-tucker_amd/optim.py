@@ -67,7 +67,7 @@ class _ManifoldOptimizer(Optimizer):
     held in persistent buffers: it is built from the tangent vector BEFORE the parameters are overwritten in place
     (the point of a tangent vector aliases the parameter storage: ``extract_tensor`` wraps ``.data``,
     ``train.py:37-42``; the reference constructs before its ``W.data.add_`` too, ``asymmetric/optim.py:109-114``)
-    and later steps ``copy_`` into the same storage, so a step captured into a HIP graph (``graphstep.py``) reads
+    and later steps ``copy_`` into the same storage, so a step captured into a HIP graph (``tools/graphstep.py``) reads
     and writes fixed addresses.  The learning rate is read from ``param_groups[0]["lr"]`` (a torch scheduler
     drives it, ``train.py:213-215``) into a device scalar outside of any capture."""
 
@@ -159,6 +159,10 @@ class _ManifoldOptimizer(Optimizer):
         for p, new in targets:
             p.data.copy_(new)
             _bump(p)
+        # x_k aliases the parameter storage that was just overwritten: what was cached on the point object for the OLD
+        # core (riemannian._point_grams: float64 Gram matrices) must not survive for a caller that reuses x_k
+        if getattr(x_k, "_core_grams64", None) is not None:
+            x_k._core_grams64 = None
         return x_new
 
 

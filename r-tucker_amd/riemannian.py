@@ -42,9 +42,12 @@ def _core_gram(core: torch.Tensor, mode: int, wide: bool = False) -> torch.Tenso
 def _point_grams(x, modes):
     """float64 core Gram matrices of a point, computed once per point object: ``fit`` projects the previous
     direction and takes the gradient at the same ``x_k`` (``asymmetric/optim.py:86-89``) and both need all of them."""
+    # keyed by the core tensor and its version counter.  (x.core aliases model.core.data, which optimizer.step()
+    # overwrites through ANOTHER .data alias -- that write is invisible to this counter, so the optimizer drops the
+    # cache itself after its write, optim._retract_and_write.)
     cache = getattr(x, "_core_grams64", None)
-    if cache is None or cache[0] is not x.core:
-        cache = (x.core, {})
+    if cache is None or cache[0] is not x.core or cache[2] != x.core._version:
+        cache = (x.core, {}, x.core._version)
         try:
             x._core_grams64 = cache
         except AttributeError:
@@ -72,6 +75,17 @@ def _solve_right(mat: torch.Tensor, gram: torch.Tensor) -> torch.Tensor:
     no factor component of its own -- the core component ``dG`` still moves it.  A zero core (trace 0) gives 0."""
     inv = spd_inverse(gram, RCOND.get(mat.dtype, 1e-8))
     return mat @ inv.to(mat.dtype)
+
+
+# Semantics of ``tucker_riemopt`` that the reference's call sites do not pin (the package is not available offline;
+# SURVEY.md Appendix C) and that decide how long a NORMALISED step is (asymmetric/optim.py:89-92).  The defaults are
+# the textbook ones; tools/train_lease.py --variant-* flips them to test the alternatives against the README recipe
+# (DESIGN.md section 8 holds the table).  Asymmetric (Tucker) geometry only.
+#   "norm": "frobenius"  -- TangentVector.norm() = Frobenius norm of the tangent vector as a tensor
+#           "coordinate" -- sqrt(|dG|^2 + sum |dU_i|^2), the norm of its coordinates
+#   "reg_in_norm": True  -- grad() differentiates the whole loss_fn (BCE + coeff |T|^2), so the norm the step is
+#                           normalised by includes the regulariser's gradient;  False -- the data term's gradient only
+EXPERIMENT = {"norm": "frobenius", "reg_in_norm": True}
 
 
 def _split_loss(loss_fn):
@@ -132,10 +146,16 @@ class TuckerTangentVector:
                                    [p + q for p, q in zip(self.delta_factors, other.delta_factors)])
 
     def norm(self) -> torch.Tensor:
+        override = getattr(self, "_norm_override", None)
+        if override is not None:
+            return override
         G = self.point.core
         s = (self.delta_core * self.delta_core).sum()
         for i, d in enumerate(self.delta_factors):
-            s = s + (_tn(d, d) * _core_gram(G, i)).sum()
+            if EXPERIMENT["norm"] == "coordinate":
+                s = s + (d * d).sum()
+            else:
+                s = s + (_tn(d, d) * _core_gram(G, i)).sum()
         return torch.sqrt(torch.clamp(s, min=0.0))
 
     def construct(self) -> Tucker:
@@ -161,12 +181,17 @@ class TuckerRiemannian:
             loss = loss_fn(T)
             grads = torch.autograd.grad(loss, [dG] + dUs, retain_graph=retain_graph)
         g_core, g_fac = grads[0], grads[1:]
+        g_core_data = g_core
         if coeff is not None:
             g_core = g_core + (2.0 * coeff) * G
             loss = loss + coeff * (G * G).sum()
         grams = _point_grams(x, range(len(Us)))
         deltas = _solve_right_many([_project_out(u, g) for u, g in zip(Us, g_fac)], grams)
-        return TuckerTangentVector(x if x.core is G else Tucker(G, Us), g_core, deltas), loss.detach()
+        pt = x if x.core is G else Tucker(G, Us)
+        tv = TuckerTangentVector(pt, g_core, deltas)
+        if coeff is not None and not EXPERIMENT["reg_in_norm"]:
+            tv._norm_override = TuckerTangentVector(pt, g_core_data, deltas).norm().detach()
+        return tv, loss.detach()
 
     @staticmethod
     def project(x: Tucker, Z: Tucker) -> TuckerTangentVector:

@@ -1,5 +1,5 @@
 """Small dense linear algebra of the Riemannian layer, written so that a whole optimizer step has NO host
-synchronisation and no eigensolver (it is captured into one HIP graph, ``graphstep.py``).
+synchronisation and no eigensolver (it can be captured into one HIP graph: tools/graphstep.py).
 
 Round 2's retraction took the left bases of the core unfoldings from ``eigh`` of their Gram matrices: rocSOLVER's
 ``syevd`` is ~15 000 tiny launches per call (80 ms in float64), the host LAPACK detour 15 ms plus a device->host
@@ -53,9 +53,15 @@ def gram_factor(S: torch.Tensor, shift: float = None, equilibrate: bool = True, 
                                                R.data_ptr(), X.data_ptr(), torch.cuda.current_stream(S.device).cuda_stream),
                        "rtk_gram_factor_f64")
         return X, R
+    # CPU / large-k fallback with the HIP kernel's no-failure semantics (csrc/rtk_chol.hip): a matrix whose trace is
+    # zero or not finite gives zero outputs; a pivot that cancelled (an indefinite or inconsistent Gram matrix) is
+    # floored at half the shift instead of failing -- here by clamping the eigenvalues of the equilibrated, shifted
+    # matrix, which leaves a positive definite input untouched to rounding
+    S64 = torch.where(torch.isfinite(S64), S64, torch.zeros_like(S64))
     diag = S64.diagonal(dim1=-2, dim2=-1)
     tr = diag.sum(-1)
-    live = (tr > 0).to(torch.float64)
+    ok = torch.isfinite(S.double().reshape(*S.shape[:-2], -1).sum(-1))
+    live = ((tr > 0) & ok).to(torch.float64)
     if equilibrate:
         d = torch.sqrt(torch.clamp(diag, min=0.0))
         ds = torch.where(d > 0, d, torch.ones_like(d))
@@ -64,6 +70,12 @@ def gram_factor(S: torch.Tensor, shift: float = None, equilibrate: bool = True, 
     Sn = S64 / (ds.unsqueeze(-1) * ds.unsqueeze(-2))
     eye = torch.eye(k, dtype=torch.float64, device=S.device)
     Sn = Sn + (sh + shift_trace * tr + (1.0 - live))[..., None, None] * eye        # (trace 0: factor I, result masked)
+    floor = 0.5 * (sh + shift_trace * tr)
+    if bool((floor > 0).any()):
+        lam, V = torch.linalg.eigh(Sn)
+        if bool((lam < floor.unsqueeze(-1)).any()):
+            lam = torch.maximum(lam, floor.unsqueeze(-1))
+            Sn = (V * lam.unsqueeze(-2)) @ V.transpose(-1, -2)
     L = torch.linalg.cholesky_ex(Sn).L
     Linv = torch.linalg.solve_triangular(L, eye.expand_as(Sn), upper=False)
     X = (Linv.transpose(-1, -2) / ds.unsqueeze(-1)) * live[..., None, None]

@@ -55,7 +55,7 @@ def _gram_norm(core: torch.Tensor, grams: Sequence[torch.Tensor]) -> torch.Tenso
 
 # Device-side health of the retraction, read (one sync) and cleared by the driver once per epoch: the largest
 # deviation from orthonormality of a new factor BEFORE its final polish, and whether anything was non-finite.
-# Nothing in a step branches on them: a step has no host synchronisation (graphstep.py captures it).
+# Nothing in a step branches on them: a step has no host synchronisation (tools/graphstep.py can capture it).
 HEALTH = {}
 
 

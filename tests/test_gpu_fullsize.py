@@ -3,7 +3,10 @@ seconds to minutes at these sizes, so only samples are evaluated exactly):
 
 * shard consistency -- the scores of a row block of O computed on their own are BIT-IDENTICAL to
   the same columns of the full computation (every entity column is scaled, split and accumulated
-  independently of the others): this is what makes entity sharding (sharded.py) exact;
+  independently of the others): this is what makes entity sharding (sharded.py) exact.  One stated
+  exception: at the WN18RR shape on one GPU the column-group kernel sums every fifth 32-column group
+  as four K-range chains (`ops.cg_fifth_group_columns`); those columns agree with the sharded run
+  to the score tolerance, all others bit for bit;
 * cross-implementation agreement -- the wave-specialised kernel, the two-workgroup kernel and
   the exact-fp32 MFMA GEMM are three independent implementations of the same product;
 * sampled entries against the float64 oracle.
@@ -37,10 +40,16 @@ def test_c2_wn18rr_full_size_properties(rt, monkeypatch):
     z = rt.score_1vN(*d, hh, rr, sigmoid=False)
     # shard consistency, ragged 8-way split like bench.py --gpus 8
     sh = rt.EntityShards(n_ent, 8)
+    from r_tucker_amd.ops import cg_fifth_group_columns
+    fifth = torch.from_numpy(cg_fifth_group_columns(n_ent, rank[2])).cuda()
+    assert 0.15 < float(fifth.float().mean()) < 0.25          # every fifth group of 32 columns
     for rank_id in (0, 3, 7):
         lo, hi = sh.bounds(rank_id)
         zs = rt.score_1vN(d[0], d[1], d[2], sh.take(d[3], rank_id), hh, rr, sigmoid=False)
-        assert torch.equal(zs[:, : hi - lo], z[:, lo:hi])
+        same = ~fifth[lo:hi]
+        assert torch.equal(zs[:, : hi - lo][:, same], z[:, lo:hi][:, same])
+        dz = (zs[:, : hi - lo] - z[:, lo:hi]).abs() / (1 + z[:, lo:hi].abs())
+        assert float(dz.max()) <= 2e-5
     # three implementations
     z_exact = rt.score_1vN(*d, hh, rr, sigmoid=False, exact=True)
     err = ((z - z_exact).abs() / (1 + z_exact.abs())).max().item()
@@ -58,8 +67,8 @@ def test_c2_wn18rr_full_size_properties(rt, monkeypatch):
 
 
 def test_c2_kernels_agree_v3_vs_ws():
-    """Same inputs through the two split-fp16 kernels (selected by RTK_SCORE_KERNEL at first use, so
-    the other one runs in a child process)."""
+    """Same inputs through the three split-fp16 kernels (selected by RTK_SCORE_KERNEL at first use, so
+    each runs in a child process, one after the other)."""
     import subprocess
     import sys
     code = r'''
@@ -72,14 +81,15 @@ z = rt.score_1vN(core, R, S, O, h, r, sigmoid=False)
 print(float(z.double().sum()), float(z.double().abs().sum()), float(z[17, 4093]), float(z[511, 40942]))
 '''
     outs = []
-    for k in ("ws", "v3"):
+    for k in ("cg", "ws", "v3"):
         env = dict(os.environ, RTK_SCORE_KERNEL=k)
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append([float(x) for x in res.stdout.strip().split()[-4:]])
-    a, b = outs
-    assert abs(a[0] - b[0]) <= 1e-6 * a[1] and abs(a[2] - b[2]) <= 2e-5 * (1 + abs(a[2])) and abs(a[3] - b[3]) <= 2e-5 * (1 + abs(a[3]))
+    a = outs[0]
+    for b in outs[1:]:
+        assert abs(a[0] - b[0]) <= 1e-6 * a[1] and abs(a[2] - b[2]) <= 2e-5 * (1 + abs(a[2])) and abs(a[3] - b[3]) <= 2e-5 * (1 + abs(a[3]))
 
 
 def test_c5_shard_bf16_full_size_properties(rt):

@@ -269,3 +269,25 @@ def test_cholesky_qr_of_a_rank_deficient_fp32_block_cpu():
     err = torch.linalg.vector_norm(Q.double() @ R - D.double(), dim=0)
     ref = torch.linalg.vector_norm(D.double(), dim=0)
     assert (err <= 2e-3 * ref + 1e-12).all(), (err / ref.clamp_min(1e-30)).max().item()
+
+
+def test_gram_factor_has_no_failure_path_on_the_cpu_either():
+    """The CPU fallback mirrors the HIP kernel (csrc/rtk_chol.hip): an INDEFINITE "Gram" matrix (a pivot cancels) is
+    floored instead of failing, a non-finite one gives zero outputs; a positive definite one is untouched."""
+    torch.manual_seed(3)
+    k = 12
+    A = torch.randn(40, k, dtype=torch.float64)
+    good = A.T @ A
+    bad = good.clone()
+    bad[3, 3] = -0.5 * good[3, 3]                       # indefinite: plain Cholesky breaks down here
+    nan = good.clone()
+    nan[5, 7] = float("nan")
+    X, R = sl.gram_factor(torch.stack([good, bad, nan]))
+    assert torch.isfinite(X).all() and torch.isfinite(R).all()
+    assert torch.equal(X[2], torch.zeros_like(X[2])) and torch.equal(R[2], torch.zeros_like(R[2]))
+    Xg, Rg = sl.gram_factor(good)
+    assert torch.allclose(X[0], Xg) and torch.allclose(R[0], Rg)
+    # the good one is a Cholesky-QR step: (A X) has orthonormal columns up to the shift
+    Q = A @ X[0]
+    assert (Q.T @ Q - torch.eye(k, dtype=torch.float64)).abs().max() < 1e-5
+    assert X[1].abs().max() < 1e8                       # bounded, however bad the input

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of the column-group score kernel (tools/ablate/build_cg_stamps.sh build): for M wave 0 and H wave 0 of
+"""Timeline of the column-group score kernel (tools/ablate/build_cg_variant.sh stamps -DRTK_CG_STAMPS build): for M wave 0 and H wave 0 of
 every workgroup, s_memtime at the prologue's barriers and at every iteration's barrier; prints the median over the
 workgroups of each event (cycles from the workgroup's own start) and the differences.
     R_TUCKER_AMD_LIB=tools/ablate/librtk_cg_stamps.so python tools/ablate/run_cg_timeline.py"""
@@ -60,8 +60,17 @@ NAMES = {0: {1: "start", 2: "S1 passed (raw set in LDS)", 7: "own group converte
          1: {1: "start", 2: "raw set written", 3: "S1 passed", 4: "S2 passed", 9: "DMA of tile i+2 issued", 10: "row factors copied", 11: "LDS reads requested", 8: "fifth group summed",
              6: "stores issued", 5: "barrier passed"}}
 BRIEF = os.environ.get("BRIEF") is not None
+# in-kernel clock: shader cycles between the first and the last s_memtime stamp of M wave 0 over the 100 MHz
+# s_memrealtime ticks between the two realtime stamps around them
+rt0 = np.array([tm[w, 0, 0] for w in range(256)])
+rtn = np.array([tm[w, 0, (code[w, 0, :] == 13).argmax()] for w in range(256)])
+c0 = np.array([tm[w, 0, 1] for w in range(256)])
+cn = np.array([tm[w, 0, (code[w, 0, :] == 13).argmax() - 1] for w in range(256)])
+print(f"in-kernel: {np.median(rtn - rt0) / 100:.2f} us of 100 MHz ticks, {np.median(cn - c0):.0f} shader cycles -> clock {np.median((cn - c0) / np.maximum(rtn - rt0, 1)) * 0.1:.3f} GHz")
+tm[:, 0, :-1] = tm[:, 0, 1:]          # drop the realtime stamp at the head of M wave 0's list
+code[:, 0, :-1] = code[:, 0, 1:]
 for role, name in ((0, "M wave 0"), (1, "S wave 0")):
-    n_ev = int((code[:, role, :] != 0).sum(axis=1).min())
+    n_ev = int(((code[:, role, :] != 0) & (code[:, role, :] != 13)).sum(axis=1).min())
     t0 = tm[:, role, 0:1]
     rel = tm[:, role, :n_ev] - t0
     med = np.median(rel, axis=0)

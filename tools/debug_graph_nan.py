@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import r_tucker_amd as rt
 from configs.base_config import wn18rr_readme_config
-from r_tucker_amd import driver, tucker, graphstep, ops
+from r_tucker_amd import driver, tucker, ops
+import graphstep
+graphstep.install()
 from r_tucker_amd.data import Data, KG_dataset
 from r_tucker_amd.utils.regularization import SimpleDecreasingPolicy
 

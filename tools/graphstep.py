@@ -1,5 +1,20 @@
-"""One Riemannian optimizer step -- ``optimizer.fit(loss_fn, x_k); optimizer.step()`` of the reference's training
-loop (``train.py:76-85``) -- captured into ONE HIP graph and replayed per batch.
+"""EXPERIMENT, not part of the product package (moved out of r-tucker_amd/ in round 4).
+
+One Riemannian optimizer step -- ``optimizer.fit(loss_fn, x_k); optimizer.step()`` of the reference's training
+loop (``train.py:76-85``) -- captured into ONE HIP graph and replayed per batch.  Opt in from a tool with
+``graphstep.install()`` (it replaces ``r_tucker_amd.driver.TRAIN_STEP_FACTORY``); ``r_tucker_amd.driver`` itself
+runs the step eagerly.
+
+Why it is out: on this stack (ROCm 7.2, torch 2.10) ``hipGraphLaunch`` of the ~470-node capture onto a stream that
+still has work queued is not ordered behind that work -- replays overlap with the previous replay (or just with the
+ids copy queued in front of them): 9 ms steps where the kernels need 15, loss sums off in the 6th digit, NaN
+parameters within 40-2000 replays.  The capture is a single chain and the launch is on the capturing stream; an
+event recorded behind the previous replay and waited for on the stream does not order it either; launching onto a
+DRAINED stream does, and so does ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` (the runtime's path that replays pre-built AQL
+packets off): the cause sits in that runtime path, not in the captured work, and the only host-side ordering that
+holds is a stream drain per replay -- which makes the replay pointless for a step that is bound by its kernels
+(15.0 ms replayed against 15.2 ms eager).  Records: profiles/r03_graph_wait_modes.log, r03_step_graph_topology.txt,
+tools/graph_event_probe.py, tools/graph_nan_bisect.py.
 
 A step at the WN18RR recipe is ~700 small launches (scores + loss + backward at doubled rank in the HIP kernels,
 tall-skinny Gram products, a few dozen 200 x 200 float64 factorizations, the truncated HOSVD of a 20 x 400 x 400
@@ -21,9 +36,14 @@ import os
 
 import torch
 
-from . import tucker as _tucker
 
 ENABLED = os.environ.get("R_TUCKER_AMD_GRAPH", "0") == "1"     # opt-in: see WAIT below and DESIGN.md section 8
+
+
+def install():
+    """Make ``r_tucker_amd.driver.train_one_epoch`` build its per-batch step through this module."""
+    from r_tucker_amd import driver
+    driver.TRAIN_STEP_FACTORY = CapturedTrainStep
 EAGER_STEPS = 2
 # How the host orders replay n behind what is already queued.  On this stack (ROCm 7.2, torch 2.10) a launch of this
 # ~470-node graph onto a stream that still has work queued -- the previous replay, or just the copy of the next batch's
@@ -133,6 +153,8 @@ class CapturedTrainStep:
             torch.cuda.synchronize(self.dev)
         elif WAIT == "stream":
             torch.cuda.current_stream(self.dev).synchronize()
+        elif WAIT != "event" or IN_FLIGHT != 1:
+            raise RuntimeError("R_TUCKER_AMD_GRAPH_WAIT must be stream | device | event (event: IN_FLIGHT = 1; known to be unsafe)")
         elif IN_FLIGHT > 0 and len(self._events) >= IN_FLIGHT:
             self._events.pop(0).synchronize()
         self.graph.replay()

@@ -10,7 +10,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import r_tucker_amd as rt                                   # noqa: E402
-from r_tucker_amd import driver, graphstep                  # noqa: E402
+from r_tucker_amd import driver
+import graphstep                                         # tools/graphstep.py (experiment)
+graphstep.install()                  # noqa: E402
 from r_tucker_amd.data import Data, KG_dataset              # noqa: E402
 from r_tucker_amd.model.asymmetric.optim import RSGDwithMomentum   # noqa: E402
 

@@ -71,12 +71,19 @@ def main():
     ap.add_argument("--lr-decay", type=float, default=None, help="per-epoch lr factor (default: the README recipe's .9981)")
     ap.add_argument("--reg-steps", type=int, default=None)
     ap.add_argument("--reg-policy", default=None, choices=["exp", "linear"])
+    ap.add_argument("--variant-norm", default="frobenius", choices=["frobenius", "coordinate"],
+                    help="what TangentVector.norm() measures (riemannian.EXPERIMENT; DESIGN.md section 8)")
+    ap.add_argument("--variant-reg-excluded", action="store_true",
+                    help="normalise the step by the DATA term's gradient norm only (riemannian.EXPERIMENT)")
     args = ap.parse_args()
     t_start = time.time()
 
     import r_tucker_amd as rt
     from configs.base_config import wn18rr_readme_config
     from r_tucker_amd import driver, tucker
+    from r_tucker_amd import riemannian as _riem
+    _riem.EXPERIMENT["norm"] = args.variant_norm
+    _riem.EXPERIMENT["reg_in_norm"] = not args.variant_reg_excluded
     from r_tucker_amd.data import Data, KG_dataset
     from r_tucker_amd.utils.regularization import SimpleDecreasingPolicy
 
@@ -162,7 +169,9 @@ def main():
     budget = args.minutes * 60.0
     epoch = epoch0
     epoch_times = []
-    from r_tucker_amd import graphstep
+    import graphstep                                    # tools/graphstep.py (experiment; same directory)
+    if graphstep.ENABLED:                               # R_TUCKER_AMD_GRAPH=1: the step replayed from a HIP graph
+        graphstep.install()
 
     def snapshot():
         return [p.detach().clone() for p in opt.param_groups[0]["params"]], (regulizer.val, regulizer.cur_step, regulizer._moves)
@@ -207,14 +216,16 @@ def main():
         if health:
             rec["retraction_health"] = max(health.values())
         log(rec)
-        if sched is not None:
-            if epoch < n_epochs:
-                sched.step()
-        else:
-            for g in opt.param_groups:
-                g["lr"] = lr_at(epoch)
         epoch_times.append(time.time() - te)
+        # the finiteness check comes BEFORE the schedule moves: a restored epoch is replayed at its own learning rate
         ok = math.isfinite(train_loss) and all(bool(torch.isfinite(p).all()) for p in opt.param_groups[0]["params"])
+        if ok:
+            if sched is not None:
+                if epoch < n_epochs:
+                    sched.step()
+            else:
+                for g in opt.param_groups:
+                    g["lr"] = lr_at(epoch)
         if not ok:
             # restore the last good epoch and go on WITHOUT the HIP graph (launches onto a busy stream)
             log({"event": "non_finite_state", "epoch": epoch, "graph_was_enabled": graphstep.ENABLED, "action": "restore + eager"})
@@ -232,11 +243,12 @@ def main():
             opt._prev = None
             graphstep.ENABLED = False
             cap = getattr(opt, "_rtk_captured", None)
-            if cap is not None:
+            if cap is not None and hasattr(cap[1], "drop_graph"):
                 cap[1].drop_graph()
             epoch -= 1
-            for g in opt.param_groups:
-                g["lr"] = lr_at(epoch)
+            if sched is None:
+                for g in opt.param_groups:
+                    g["lr"] = lr_at(epoch)
             continue
         good = snapshot()
     save(epoch)
