@@ -189,8 +189,12 @@ def main():
                     help="bf16 workloads: dtype of the score matrix (bf16 = what the reference's bf16 model returns; halves the exchange)")
     ap.add_argument("--tables", choices=["cached", "per-batch"], default="cached",
                     help="relation tables: built once per evaluation pass of %d batches (default) or in every step" % EVAL_BATCHES)
-    ap.add_argument("--stage1", choices=["auto", "replicated", "split"], default="auto",
-                    help="multi-GPU: query vectors computed by every rank, or batch-split + all-gather (auto: split for relation rank > 32)")
+    ap.add_argument("--stage1", choices=["auto", "replicated", "split", "relation"], default="auto",
+                    help="multi-GPU: query vectors computed by every rank, batch-split + all-gather, or split by relation id + "
+                         "all-reduce (auto: relation split for relation rank > 32 with cached tables, else batch split)")
+    ap.add_argument("--emulate-ranks", type=int, default=8,
+                    help="N = 1, the one-GPU share of configs[4]: also time ONE rank's step of an N-rank run (stage 1 for the "
+                         "relations of rank 0 only, pack, score the shard; no collective) -> emulated_per_gpu_ms_per_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-ms", type=float, default=1000.0,
                     help="untimed clock ramp before the --warmup steps: the same steps for this long (a 20-step run is "
@@ -287,7 +291,9 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
     cached = args.tables == "cached"
-    split1 = world > 1 and (args.stage1 == "split" or (args.stage1 == "auto" and a > 32))
+    split1 = world > 1 and (args.stage1 in ("split", "relation") or (args.stage1 == "auto" and a > 32))
+    by_rel = split1 and cached and args.stage1 in ("relation", "auto")
+    ftp_fn = lib.rtk_query_vectors_from_tables_part_bf16 if bf16 else lib.rtk_query_vectors_from_tables_part_f32
     ws_bytes = max(lib.rtk_workspace_bytes(dcode, B, n_rel, a, b, c), lib.rtk_from_tables_workspace_bytes(B, n_rel))
     ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
     qp = torch.empty(lib.rtk_packed_query_bytes(dcode, B, c), dtype=torch.uint8, device=dev)
@@ -304,10 +310,20 @@ def main():
     # stage 1 split over the ranks: this rank's slice of the batch, the gathered (B_loc * world, c) vectors
     B_loc = -(-B // world)
     qlo, qhi = min(rank * B_loc, B), min((rank + 1) * B_loc, B)
-    v_all = torch.zeros((world * B_loc, c), dtype=torch.float32, device=dev) if split1 else None
+    v_all = torch.zeros((max(world * B_loc, B), c), dtype=torch.float32, device=dev) if split1 else None
 
     def stage1(h, r, cached=cached, want_v=args.exact):
         """query vectors of the batch -> packed planes in qp (and/or fp32 v)"""
+        if by_rel:
+            # stage 1 split by relation id: this rank's relations only, rows of the others stay zero; one all-reduce
+            vr = v_all[:B]
+            vr.zero_()
+            _lib.check(ftp_fn(tables.data_ptr(), n_rel, b, c, S.data_ptr(), n_ent, r.data_ptr(), h.data_ptr(), B, rank, world,
+                              vr.data_ptr(), ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_from_tables_part")
+            dist.all_reduce(vr)
+            if not args.exact:
+                _lib.check(lib.rtk_pack_query_vectors(vr.data_ptr(), B, c, dcode, qp.data_ptr(), sp), "rtk_pack_query_vectors")
+            return vr
         if split1:
             nq = qhi - qlo
             mine = v_all[rank * B_loc:(rank + 1) * B_loc]
@@ -451,6 +467,41 @@ def main():
             extras.update(surface_timings(rt, core, R, S, O, sym, pool, n_ent, n_rel, trank, B, args.workload, dev))
         except Exception as e:       # the headline line must survive a failure of this extra leg
             extras["surface_error"] = repr(e)
+        if "shard" in args.workload and cached and args.emulate_ranks > 1:
+            # ONE rank's step of an --emulate-ranks-rank run on this GPU's entity shard: stage 1 for the relations of rank 0
+            # (rtk_query_vectors_from_tables_part_*), pack, score.  The all-reduce of the B x c vectors (16 MB at configs[4])
+            # that a real run adds is NOT in it: an emulation of the per-GPU compute, not a multi-GPU measurement.
+            # (The packing and the score kernel run on the COMPLETE vectors of the batch, computed beforehand -- what the
+            # all-reduce would have delivered: seven eighths of the rows left at zero would let the score kernel run on zero
+            # operands, which the chip clocks ~10 % faster.)
+            ve = torch.zeros((B, c), dtype=torch.float32, device=dev)
+            ftp = lib.rtk_query_vectors_from_tables_part_bf16 if bf16 else lib.rtk_query_vectors_from_tables_part_f32
+            v_full = []
+            for i in range(len(pool)):
+                h, r = pool[i]
+                vf = torch.empty((B, c), dtype=torch.float32, device=dev)
+                _lib.check(ft_fn(tables.data_ptr(), n_rel, b, c, S.data_ptr(), n_ent, r.data_ptr(), h.data_ptr(), B, vf.data_ptr(), None,
+                                 ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_from_tables")
+                v_full.append(vf)
+
+            def step_emulated(i):
+                h, r = pool[i % len(pool)]
+                ve.zero_()
+                _lib.check(ftp(tables.data_ptr(), n_rel, b, c, S.data_ptr(), n_ent, r.data_ptr(), h.data_ptr(), B, 0,
+                               args.emulate_ranks, ve.data_ptr(), ws.data_ptr(), ws.numel(), sp), "rtk_query_vectors_from_tables_part")
+                _lib.check(lib.rtk_pack_query_vectors(v_full[i % len(pool)].data_ptr(), B, c, dcode, qp.data_ptr(), sp), "rtk_pack_query_vectors")
+                _lib.check(sp_fn(qp.data_ptr(), B, c, O_loc.data_ptr(), n_loc, out.data_ptr(), pitch, sflags, sp), "rtk_score_packed")
+
+            n_e = max(10, min(args.steps, 100))
+            for i in range(5):
+                step_emulated(i)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(n_e):
+                step_emulated(i)
+            barrier()
+            extras["emulated_per_gpu_ms_per_step"] = (time.perf_counter() - t1) / n_e * 1e3
+            extras["emulated_ranks"] = args.emulate_ranks
         if not bf16 and c <= 512:
             ex = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(12)]
             for e2 in ex:
@@ -493,7 +544,8 @@ def main():
                    "prewarm_ms": args.prewarm_ms,
                    "relation_tables": (f"cached: rebuilt every {EVAL_BATCHES} steps inside the timed region" if cached
                                        else "rebuilt in every step"),
-                   "stage1": "batch split over ranks + all-gather of the query vectors" if split1 else "on every rank",
+                   "stage1": ("split over ranks by relation id + all-reduce of the query vectors" if by_rel else
+                              "batch split over ranks + all-gather of the query vectors" if split1 else "on every rank"),
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
         "scores_per_s": args.steps * B * n_ent / dt,
         **extras,

@@ -162,6 +162,26 @@ int rtk_query_vectors_from_tables_bf16(const float *tables, int64_t n_rel, int b
                                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The same step restricted to the queries whose relation id is congruent to `part` modulo `n_parts`: their rows of
+ * v_out (B x c fp32, required) are written, every other row is left untouched.  This is stage 1 split over the ranks
+ * of an entity-sharded run BY RELATION: a rank then streams only the tables of its own relations
+ * (1/n_parts of rtk_relation_tables_bytes instead of nearly all of it when the batch is split by position: at
+ * BASELINE.json configs[4], 8192 queries over 1000 relations, a batch slice of 1024 queries still touches ~640
+ * tables of 1 MB); the B x c vectors are completed by one all-reduce(SUM) over buffers zeroed before the call --
+ * every row is non-zero on exactly one rank, so the sum is exact -- and packed with rtk_pack_query_vectors.
+ */
+int rtk_query_vectors_from_tables_part_f32(const float *tables, int64_t n_rel, int b, int c,
+                                           const float *S, int64_t n_sub,
+                                           const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                                           int part, int n_parts, float *v_out,
+                                           void *workspace, size_t workspace_bytes, void *stream);
+int rtk_query_vectors_from_tables_part_bf16(const float *tables, int64_t n_rel, int b, int c,
+                                            const void *S, int64_t n_sub,
+                                            const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch,
+                                            int part, int n_parts, float *v_out,
+                                            void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Stage 2: scores  out[d, j] = sigmoid( v[d,:] . O[j,:] )   for j < n_local
  * replaces asymmetric/R_TuckER.py:47-48 ( @ T.factors[2].T ; sigmoid ) and
  * symmetric/R_TuckER.py:44-45.  `O` is the (shard of the) entity matrix,

@@ -53,6 +53,8 @@ SIGNATURES = {
     "rtk_relation_tables_bf16": (_i, [_p, _i, _i, _i, _p, _i64, _p, _p, _sz, _p]),
     "rtk_query_vectors_from_tables_f32": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     "rtk_query_vectors_from_tables_bf16": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "rtk_query_vectors_from_tables_part_f32": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _i, _i, _p, _p, _sz, _p]),
+    "rtk_query_vectors_from_tables_part_bf16": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _i, _i, _p, _p, _sz, _p]),
     "rtk_sigmoid_grad_f32": (_i, [_p, _p, _p, _i64, _p]),
     "rtk_sigmoid_grad_rows_f32": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
     "rtk_filtered_rank_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),

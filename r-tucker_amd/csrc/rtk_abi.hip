@@ -68,10 +68,10 @@ int rtk_relation_tables_bf16_impl(const void *core, int a, int b, int c, const v
                                   void *core_t, void *r_packed, hipStream_t st);
 int rtk_from_tables_f32_impl(const float *tables, int64_t n_rel, int b, int c, const float *S, int64_t n_sub,
                              const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
-                             void *q_packed, const RtkWorkspace &ws, hipStream_t st);
+                             void *q_packed, const RtkWorkspace &ws, hipStream_t st, int rel_part = 0, int rel_parts = 1);
 int rtk_from_tables_bf16_impl(const float *tables, int64_t n_rel, int b, int c, const void *S, int64_t n_sub,
                               const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
-                              void *q_packed, const RtkWorkspace &ws, hipStream_t st);
+                              void *q_packed, const RtkWorkspace &ws, hipStream_t st, int rel_part = 0, int rel_parts = 1);
 
 // scratch of the tables build: only the bf16 large-relation-rank path needs any (transposed core, packed R rows)
 struct TablesWs {
@@ -195,7 +195,35 @@ extern "C" int rtk_query_vectors_from_tables_bf16(const float *tables, int64_t n
                                      carve_ft(workspace, batch, n_rel), (hipStream_t)stream);
 }
 
-extern "C" int rtk_version(void) { return 200; }
+// Stage 1 split over ranks BY RELATION: only the queries whose relation id is congruent to `part` modulo `n_parts`
+// are contracted, into their rows of v_out; every other row of v_out is left untouched.
+extern "C" int rtk_query_vectors_from_tables_part_f32(const float *tables, int64_t n_rel, int b, int c, const float *S,
+                                                      int64_t n_sub, const int64_t *rel_idx, const int64_t *sub_idx,
+                                                      int64_t batch, int part, int n_parts, float *v_out, void *workspace,
+                                                      size_t workspace_bytes, void *stream) {
+    int rc = check_ft("rtk_query_vectors_from_tables_part_f32", tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out,
+                      nullptr, workspace, workspace_bytes);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(v_out && n_parts >= 1 && part >= 0 && part < n_parts, RTK_ERR_BAD_ARG,
+                "rtk_query_vectors_from_tables_part_f32: v_out must be given, 0 <= part < n_parts");
+    return rtk_from_tables_f32_impl(tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out, nullptr,
+                                    carve_ft(workspace, batch, n_rel), (hipStream_t)stream, part, n_parts);
+}
+
+extern "C" int rtk_query_vectors_from_tables_part_bf16(const float *tables, int64_t n_rel, int b, int c, const void *S,
+                                                       int64_t n_sub, const int64_t *rel_idx, const int64_t *sub_idx,
+                                                       int64_t batch, int part, int n_parts, float *v_out, void *workspace,
+                                                       size_t workspace_bytes, void *stream) {
+    int rc = check_ft("rtk_query_vectors_from_tables_part_bf16", tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out,
+                      nullptr, workspace, workspace_bytes);
+    if (rc != RTK_OK) return rc;
+    RTK_REQUIRE(v_out && n_parts >= 1 && part >= 0 && part < n_parts, RTK_ERR_BAD_ARG,
+                "rtk_query_vectors_from_tables_part_bf16: v_out must be given, 0 <= part < n_parts");
+    return rtk_from_tables_bf16_impl(tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out, nullptr,
+                                     carve_ft(workspace, batch, n_rel), (hipStream_t)stream, part, n_parts);
+}
+
+extern "C" int rtk_version(void) { return 210; }
 extern "C" const char *rtk_last_error_string(void) { return g_err; }
 
 extern "C" size_t rtk_workspace_bytes(int dtype, int64_t batch, int64_t n_rel, int a, int b, int c) {

@@ -367,7 +367,8 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
                                                        float *__restrict__ v_out,
                                                        unsigned char *__restrict__ q_packed, int ksteps,
                                                        uint32_t *__restrict__ flags,
-                                                       const int64_t *__restrict__ qinfo, int B) {
+                                                       const int64_t *__restrict__ qinfo, int B,
+                                                       int rel_part, int rel_parts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *part = smem;                       // G * cpad floats, later the finished row
     __shared__ float red[4];
@@ -400,6 +401,9 @@ __global__ __launch_bounds__(256) void contract_kernel(const float *__restrict__
     bool bad = false;
     if (h < 0 || h >= n_sub) { bad = true; h = 0; }
     if (r < 0 || r >= n_rel) { bad = true; r = 0; }
+    // stage 1 split over ranks BY RELATION (rel_parts > 1): this launch only contracts the queries whose relation id
+    // is congruent to rel_part; the rows of the others are left as they are (a bad id counts as relation 0)
+    if (rel_parts > 1 && (int)(r % rel_parts) != rel_part) return;
     if (bad && t == 0) atomicOr(&flags[0], 1u);
     if (slot < 0) slot = slot_of_rel ? max(slot_of_rel[r], 0) : (int)r;
     const float *Mq = M + (int64_t)slot * b * c;
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
     const float *__restrict__ M, int b, int c, const T *__restrict__ S, int64_t n_sub,
     const int64_t *__restrict__ rel_idx, const int64_t *__restrict__ sub_idx, int n_rel,
     const int32_t *__restrict__ work, const int32_t *__restrict__ order, float *__restrict__ v_out,
-    unsigned char *__restrict__ q_packed, int ksteps, uint32_t *__restrict__ flags) {
+    unsigned char *__restrict__ q_packed, int ksteps, uint32_t *__restrict__ flags, int rel_part, int rel_parts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[4][QG];
     __shared__ int qid[QG];
@@ -516,6 +520,9 @@ __global__ __launch_bounds__(256) void contract_grouped_kernel(
     if ((int)(blockIdx.x >> 3) >= n8 || item >= n_work) return;
     const int32_t *wk = work + 4 * (int64_t)item;
     const int slot = wk[0], q0 = wk[1], nq = wk[2];
+    // stage 1 split over ranks by relation (the slot IS the relation id where this is used: prebuilt tables): the work
+    // items of the other ranks' relations end here, before their table is touched
+    if (rel_parts > 1 && slot % rel_parts != rel_part) return;
     const int bpad = (b + 3) & ~3;
     const int cols = (c + W - 1) / W, cpad = cols * W;   // cols <= 256 (host)
     const int ngroups = 256 / cols;
@@ -827,12 +834,12 @@ static int contract_stage(const float *tables, int b, int c, const T *S, int64_t
                           const int64_t *sub_idx, int64_t n_rel, int64_t batch, const int32_t *slot_of_rel,
                           int n_slots, const ContractPlan &cp, bool have_groups, const int32_t *grp_work,
                           const int32_t *grp_order, const int64_t *grp_qinfo, uint32_t *flags, float *v_out,
-                          void *q_packed, hipStream_t st) {
+                          void *q_packed, hipStream_t st, int rel_part = 0, int rel_parts = 1) {
     const int ksteps = (c + 15) / 16;
     if (cp.grouped) {
         RTK_REQUIRE(have_groups, RTK_ERR_BAD_ARG, "rtk_query_vectors: grouped contract without groups");
         const unsigned nwg = (unsigned)(batch / cp.QG + (n_slots < batch ? n_slots : batch) + 8);   // upper bound on the work items, rounded up to 8 (flags[2] holds the count)
-#define RTK_CG(V_, Q_) hipLaunchKernelGGL((contract_grouped_kernel<T, V_, Q_>), dim3(nwg), dim3(256), cp.smem_grouped, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, grp_work, grp_order, v_out, (unsigned char *)q_packed, ksteps, flags)
+#define RTK_CG(V_, Q_) hipLaunchKernelGGL((contract_grouped_kernel<T, V_, Q_>), dim3(nwg), dim3(256), cp.smem_grouped, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, grp_work, grp_order, v_out, (unsigned char *)q_packed, ksteps, flags, rel_part, rel_parts)
         if (cp.QG == 16) {
             static std::atomic<unsigned long long> ok_v{0}, ok_s{0};
             const int rc = cp.cvec ? rtk_ensure_dynamic_lds(reinterpret_cast<const void *>(&contract_grouped_kernel<T, true, 16>), (int)GROUPED16_LDS_MAX, ok_v, "contract_grouped_kernel")
@@ -851,8 +858,8 @@ static int contract_stage(const float *tables, int b, int c, const T *S, int64_t
     RTK_REQUIRE(smem <= 64 * 1024, RTK_ERR_UNSUPPORTED, "rtk_query_vectors: rank too large for the contract kernel (b=%d c=%d)", b, c);
     const int64_t *pq_order = have_groups ? grp_qinfo : nullptr;
     const unsigned pq_grid = (unsigned)(have_groups ? rtk_cdiv(batch, 8) * 8 : batch);
-    if (cp.cvec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3(pq_grid), dim3(256), smem, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, slot_of_rel, v_out, (unsigned char *)q_packed, ksteps, flags, pq_order, (int)batch);
-    else hipLaunchKernelGGL((contract_kernel<T, false>), dim3(pq_grid), dim3(256), smem, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, slot_of_rel, v_out, (unsigned char *)q_packed, ksteps, flags, pq_order, (int)batch);
+    if (cp.cvec) hipLaunchKernelGGL((contract_kernel<T, true>), dim3(pq_grid), dim3(256), smem, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, slot_of_rel, v_out, (unsigned char *)q_packed, ksteps, flags, pq_order, (int)batch, rel_part, rel_parts);
+    else hipLaunchKernelGGL((contract_kernel<T, false>), dim3(pq_grid), dim3(256), smem, st, tables, b, c, S, n_sub, rel_idx, sub_idx, (int)n_rel, slot_of_rel, v_out, (unsigned char *)q_packed, ksteps, flags, pq_order, (int)batch, rel_part, rel_parts);
     return rtk_check_launch("rtk_query_vectors");
 }
 
@@ -898,7 +905,7 @@ static int relation_tables_impl(const T *core, int a, int b, int c, const T *R, 
 template <typename T>
 static int from_tables_impl(const float *tables, int64_t n_rel, int b, int c, const T *S, int64_t n_sub,
                             const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
-                            void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
+                            void *q_packed, const RtkWorkspace &ws, hipStream_t st, int rel_part = 0, int rel_parts = 1) {
     const ContractPlan cp = plan_contract(b, c, batch, tables, n_rel);
     static const bool order_small = getenv("RTK_FT_ORDER") != nullptr;   // A/B: slot order for the per-query kernel too
     const bool groups = cp.grouped || order_small;
@@ -908,7 +915,7 @@ static int from_tables_impl(const float *tables, int64_t n_rel, int b, int c, co
         hipLaunchKernelGGL(groups_kernel, dim3(1), dim3(1024), 0, st, ga);
     }
     return contract_stage<T>(tables, b, c, S, n_sub, rel_idx, sub_idx, n_rel, batch, nullptr, (int)n_rel, cp, groups,
-                             ws.grp_work, ws.grp_order, ws.grp_qinfo, ws.flags, v_out, q_packed, st);
+                             ws.grp_work, ws.grp_order, ws.grp_qinfo, ws.flags, v_out, q_packed, st, rel_part, rel_parts);
 }
 
 int rtk_query_vectors_f32_impl(const float *core, int a, int b, int c, const float *R, int64_t n_rel,
@@ -939,15 +946,16 @@ int rtk_relation_tables_bf16_impl(const void *core, int a, int b, int c, const v
 
 int rtk_from_tables_f32_impl(const float *tables, int64_t n_rel, int b, int c, const float *S, int64_t n_sub,
                              const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
-                             void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
-    return from_tables_impl<float>(tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed, ws, st);
+                             void *q_packed, const RtkWorkspace &ws, hipStream_t st, int rel_part, int rel_parts) {
+    return from_tables_impl<float>(tables, n_rel, b, c, S, n_sub, rel_idx, sub_idx, batch, v_out, q_packed, ws, st, rel_part,
+                                   rel_parts);
 }
 
 int rtk_from_tables_bf16_impl(const float *tables, int64_t n_rel, int b, int c, const void *S, int64_t n_sub,
                               const int64_t *rel_idx, const int64_t *sub_idx, int64_t batch, float *v_out,
-                              void *q_packed, const RtkWorkspace &ws, hipStream_t st) {
+                              void *q_packed, const RtkWorkspace &ws, hipStream_t st, int rel_part, int rel_parts) {
     return from_tables_impl<rtk_bf16>(tables, n_rel, b, c, (const rtk_bf16 *)S, n_sub, rel_idx, sub_idx, batch, v_out,
-                                      q_packed, ws, st);
+                                      q_packed, ws, st, rel_part, rel_parts);
 }
 
 extern "C" int rtk_pack_query_vectors(const float *v, int64_t batch, int c, int dtype, void *q_packed, void *stream) {

@@ -592,6 +592,36 @@ def score_1vN_into(core, R, S, O, subject_idx, relation_idx, out, sigmoid=True, 
     return out
 
 
+def query_vectors_part(core, R, S, subject_idx, relation_idx, tables, part, n_parts, out):
+    """Stage 1 for the queries whose relation id is congruent to ``part`` modulo ``n_parts`` only, against the prebuilt
+    relation ``tables``: their rows of ``out`` (B, c) fp32 are written, the others left untouched
+    (``rtk_query_vectors_from_tables_part_*``; the entity-sharded scorer's ``stage1="relation"``)."""
+    lib = _lib.load()
+    _require_gpu("core", core)
+    bf16 = core.dtype == torch.bfloat16
+    dt = core.dtype
+    core, R, S = _operand("core", core, dt), _operand("R", R, dt), _operand("S", S, dt)
+    dev = core.device
+    a, b, c = core.shape
+    h, r = _idx("subject_idx", subject_idx, dev), _idx("relation_idx", relation_idx, dev)
+    B = h.numel()
+    if tuple(out.shape) != (B, c) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+        raise RuntimeError(f"out must be a contiguous float32 ({B}, {c}) tensor on {dev}")
+    if tables is None or tuple(tables.shape) != (R.shape[0], b, c) or tables.dtype != torch.float32 or not tables.is_contiguous():
+        raise RuntimeError("query_vectors_part needs the prebuilt relation tables (ops.relation_tables)")
+    if B == 0:
+        return out
+    with torch.cuda.device(dev):
+        sp = _stream_ptr(dev)
+        ws = _workspace(dev, sp, _size("rtk_from_tables_workspace_bytes", B, R.shape[0]))
+        fn = lib.rtk_query_vectors_from_tables_part_bf16 if bf16 else lib.rtk_query_vectors_from_tables_part_f32
+        _lib.check(fn(tables.data_ptr(), R.shape[0], b, c, S.data_ptr(), S.shape[0], r.data_ptr(), h.data_ptr(), B,
+                      int(part), int(n_parts), out.data_ptr(), ws.data_ptr(), ws.numel(), sp),
+                   "rtk_query_vectors_from_tables_part")
+        _strict_check(dev, ws, sp)
+    return out
+
+
 def query_vectors(core, R, S, subject_idx, relation_idx, tables=None, packed=False):
     """Stage 1 only: ``v[d] = S[h_d] . (G x_0 R[r_d])`` -> ``(B, c)`` fp32 (R_TuckER.py:43-46).
     ``packed=True`` returns ``(v, q_packed)`` with the packed query planes the score kernels consume."""

@@ -412,6 +412,32 @@ def test_c4_fb15k_eight_way_shard_consistency(rt, B):
     assert (full.cpu()[rows] - ref).abs().max().item() <= 3e-6
 
 
+@pytest.mark.parametrize("B,bf16", [(300, False), (2500, True)])      # the per-query and the grouped contract kernel
+def test_stage1_by_relation_parts_reassemble_the_full_vectors(rt, B, bf16):
+    """rtk_query_vectors_from_tables_part_*: the rows of the queries with relation id = part (mod n_parts), nothing
+    else; the n_parts launches together give the unsplit stage 1 bit for bit (what the all-reduce(SUM) of the entity-
+    sharded scorer's stage1="relation" adds up)."""
+    from r_tucker_amd import ops
+    n_ent, n_rel, rank = 900, 37, (40, 64, 64)
+    core, R, S, O = dev(*gen.make_params(n_ent, n_rel, rank, 9))
+    if bf16:
+        core, R, S = core.bfloat16(), R.bfloat16(), S.bfloat16()
+    h, r = dev(*gen.make_queries(n_ent, n_rel, B, 9))
+    tables = rt.relation_tables(core, R)
+    full = ops.query_vectors(core, R, S, h, r, tables=tables)
+    P = 8
+    acc = torch.zeros_like(full)
+    for p in range(P):
+        part = torch.full_like(full, 7.0)
+        ops.query_vectors_part(core, R, S, h, r, tables, p, P, part)
+        sel = (r % P) == p
+        assert torch.equal(part[sel], full[sel])
+        assert torch.all(part[~sel] == 7.0)                    # untouched
+        part[~sel] = 0
+        acc += part
+    assert torch.equal(acc, full)
+
+
 def test_pack_query_vectors_matches_stage1_planes(rt):
     """rtk_pack_query_vectors writes the planes rtk_query_vectors_* writes (fp32 hi/lo and bf16)."""
     for dt, rank in ((torch.float32, (5, 72, 72)), (torch.bfloat16, (5, 72, 72)), (torch.float32, (4, 200, 200))):

@@ -84,6 +84,54 @@ def _split_worker(rank, world, port, n_ent, B, q):
         dist.destroy_process_group()
 
 
+def _relation_worker(rank, world, port, n_ent, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from r_tucker_amd.sharded import ShardedEntityScorer
+        n_rel, rank3 = 5, (3, 8, 8)
+        core, R, S, O = [torch.from_numpy(x) for x in gen.make_params(n_ent, n_rel, rank3, 13)]
+        h, r = [torch.from_numpy(x) for x in gen.make_queries(n_ent, n_rel, B, 13)]
+        tables = torch.einsum("ua,abc->ubc", R, core)
+        mine = []
+
+        def qv_part(core_, R_, S_, hh, rr, tables_, part, n_parts, out):     # the C ABI's contract on the CPU
+            sel = (rr % n_parts) == part
+            mine.append(int(sel.sum()))
+            if sel.any():
+                out[sel] = torch.einsum("db,dbc->dc", S_[hh[sel]], tables_[rr[sel]])
+            return out
+
+        def score_from_v(v, O_loc, out, **kw):
+            out.copy_(torch.sigmoid(v @ O_loc.T))
+
+        sc = ShardedEntityScorer(n_ent, local_score=_oracle_local, stage1="relation", score_from_v_fn=score_from_v)
+        sc.query_vectors_part_fn = qv_part
+        P = sc.score(core, R, S, sc.local_block(O), h, r, tables=tables)
+        ref = orc.score_ref(core, R, S, O, h, r)
+        ok = torch.allclose(P, ref, atol=1e-5) and mine == [int(((r % world) == rank).sum())]
+        q.put((rank, bool(ok), float((P - ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ent,B", [(64, 9), (37, 1)])
+def test_sharded_stage1_by_relation_world2_gloo(n_ent, B):
+    """Stage 1 split over the ranks by relation id (rank p: relations congruent to p), one all-reduce(SUM) of the
+    zero-initialised B x c vectors, stage 2 on the local entity shard: same matrix as the oracle on one device."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_relation_worker, args=(rk, 2, port, n_ent, B, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert [r[1] for r in res] == [True, True], res
+
+
 @pytest.mark.parametrize("n_ent,B", [(64, 9), (101, 2), (37, 1)])   # ragged batch slices, an empty slice, ragged shards
 def test_sharded_stage1_split_world2_gloo(n_ent, B):
     """Stage 1 split over the ranks (each contracts ceil(B/P) queries, one all-gather of the B x c vectors),
