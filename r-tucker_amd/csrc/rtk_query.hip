@@ -880,13 +880,19 @@ static int query_vectors_impl(const T *core, int a, int b, int c, const T *R, in
     const ContractPlan cp = plan_contract(b, c, batch, ws.tables, n_u_max);
     // the slot order is built either way: the per-query kernel uses it to keep a table in one XCD's L2
     // (the per-position (subject, query, slot) records are only read by the per-query contract kernel)
+    // The slot order of the queries rides in the first kernel of the table build (one extra workgroup, no launch).  For
+    // the per-query contract kernel it is only worth L2 locality (~1.8 us at B = 512), and at a small relation rank the
+    // one-workgroup sort IS the tables kernel's critical path (7.4 us against ~4 without it): built there only when the
+    // table build is a GEMM (a > 32).  WN18RR per-batch step 49.0 -> 46.9 us on one box (RTK_PB_GROUPS=1 / 0 force it).
+    static const int pb_env = getenv("RTK_PB_GROUPS") ? atoi(getenv("RTK_PB_GROUPS")) : -1;
+    const bool groups = cp.grouped || (pb_env < 0 ? a > 32 : pb_env != 0);
     GroupArgs ga{rel_idx, planned ? ws.slot_of_rel : nullptr, ws.grp_cnt, ws.grp_order, ws.grp_work, ws.flags,
-                 (int)batch, (int)n_rel, n_u_max, cp.QG, sub_idx, cp.grouped ? nullptr : ws.grp_qinfo};
+                 (int)batch, (int)n_rel, n_u_max, groups ? cp.QG : 0, sub_idx, cp.grouped ? nullptr : ws.grp_qinfo};
     int rc = build_tables<T>(core, a, b, c, R, n_rel, planned ? ws.rel_list : nullptr, n_u_max,
                              planned ? ws.flags + 1 : nullptr, ws.tables, ws.core_t, ws.r_packed, ga, st);
     if (rc != RTK_OK) return rc;
     return contract_stage<T>(ws.tables, b, c, S, n_sub, rel_idx, sub_idx, n_rel, batch,
-                             planned ? ws.slot_of_rel : nullptr, n_u_max, cp, true, ws.grp_work, ws.grp_order,
+                             planned ? ws.slot_of_rel : nullptr, n_u_max, cp, groups, ws.grp_work, ws.grp_order,
                              ws.grp_qinfo, ws.flags, v_out, q_packed, st);
 }
 
