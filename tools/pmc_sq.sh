@@ -6,7 +6,7 @@ TAG=$1
 WL=${2:-wn18rr_asym_r10x200_b512_f32}
 STEPS=${3:-25}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/pmcsq_$TAG
+OUT=/tmp/pmcsq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"

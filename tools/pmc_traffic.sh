@@ -5,7 +5,7 @@
 set -e
 TAG=$1; ENVS=$2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/pmc_$TAG
+OUT=/tmp/pmc_$TAG
 mkdir -p $OUT
 WL=${WORKLOAD:-wn18rr_asym_r10x200_b512_f32}
 cd /tmp && export TMPDIR=/tmp
