@@ -1,8 +1,10 @@
 """MRR parity on a TRAINED model that ranks (north_star: filtered MRR through the HIP path within +-0.001 of the CPU
-restatement of the reference's op sequence, on the same parameters).  Needs a checkpoint written by
-tools/train_lease.py -- 51 MB, not committed: point ``R_TUCKER_AMD_CKPT`` at it (or leave one under ``ckpt_tmp/``);
-skipped otherwise.  tests/test_gpu_trained.py makes the same checks on a model trained inside the test (MRR 0.03);
-this one ran on the WN18RR model of DESIGN.md section 8 and its output is profiles/r03_trained_checkpoint_parity.json."""
+restatement of the reference's op sequence, on the same parameters).  Runs from a clean clone on the committed fixture
+tests/golden/wn18rr_trained_q8.npz (16 MB: the epoch-500 WN18RR model of DESIGN.md section 8 with its two factor
+matrices as int8 + one scale per row, written by tools/pack_checkpoint_q8.py; MRR 0.44 like the original), or on a
+full checkpoint of tools/train_lease.py (51 MB, not committed) when ``R_TUCKER_AMD_CKPT`` points at one or one lies
+under ``ckpt_tmp/``.  tests/test_gpu_trained.py makes the same checks on a model trained inside the test (MRR 0.03).
+Outputs: profiles/r03_trained_checkpoint_parity.json (full checkpoint), profiles/r04_trained_q8_parity.json (fixture)."""
 import glob
 import json
 import os
@@ -23,19 +25,29 @@ def _checkpoint():
     if p:
         return p
     found = sorted(glob.glob(os.path.join(ROOT, "ckpt_tmp", "*.npz")))
-    return found[-1] if found else None
+    return found[-1] if found else FIXTURE
+
+
+FIXTURE = os.path.join(ROOT, "tests", "golden", "wn18rr_trained_q8.npz")
+
+
+def _factors(z):
+    """(S, O) as float32 tensors from either container."""
+    if "S_q8" in z.files:
+        from pack_checkpoint_q8 import dequantise
+        return [torch.from_numpy(dequantise(z[n + "_q8"], z[n + "_scale"])) for n in ("S", "O")]
+    from train_lease import unpack24
+    return [unpack24(z[n]) for n in ("S", "O")]
 
 
 @pytest.mark.parametrize("split", ["test", "valid"])
 def test_trained_checkpoint_mrr_parity(split):
     path = _checkpoint()
-    if not path or not os.path.exists(path):
-        pytest.skip("no trained checkpoint (R_TUCKER_AMD_CKPT / ckpt_tmp/*.npz)")
+    assert os.path.exists(path), path
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import r_tucker_amd as rt
     from configs.base_config import wn18rr_readme_config
     from r_tucker_amd.data import Data, KG_dataset
-    from train_lease import unpack24
     data = Data(os.path.join(ROOT, "data", "WN18RR") + "/", reverse=True)
     rank = wn18rr_readme_config().model_cfg.manifold_rank
     model = rt.AsymmetricR_TuckER((len(data.entities), len(data.relations)), rank)
@@ -44,8 +56,8 @@ def test_trained_checkpoint_mrr_parity(split):
     with torch.no_grad():
         model.core.copy_(torch.from_numpy(z["core"]))
         model.R.weight.copy_(torch.from_numpy(z["R"]))
-        for name, w in (("S", model.S.weight), ("O", model.O.weight)):
-            q, r_ = torch.linalg.qr(unpack24(z[name]).double())
+        for raw, w in zip(_factors(z), (model.S.weight, model.O.weight)):
+            q, r_ = torch.linalg.qr(raw.double())
             w.copy_((q * torch.sign(torch.diagonal(r_))).float())
     model.cuda()
     ev_set = KG_dataset(data, data.test_data if split == "test" else data.valid_data, test_set=True)
@@ -95,6 +107,7 @@ def test_trained_checkpoint_mrr_parity(split):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"trained_checkpoint_parity_{split}.json"), "w") as f:
         json.dump(out, f, indent=1)
+    assert out["cpu_oracle"]["mrr"] > 0.4, out              # a model that ranks, not the chance level
     assert abs(out["device"]["mrr"] - out["evaluate()"]["mrr"]) < 1e-9
     assert out["mrr_difference"] <= 1e-3, out
     assert out["within_score_tolerance_bracket"] >= 0.999, out
