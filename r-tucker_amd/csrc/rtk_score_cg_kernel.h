@@ -76,10 +76,15 @@ constexpr int MISC_BYTES = 640;
 template <int KS>
 __host__ __device__ constexpr int tile_bytes() { return RTK_PACK_HDR + 2 * KS * 1024; }
 
+// Row pitch (floats) of the raw set in LDS: c plus four.  A lane of the conversion reads 16 B of "its" row, 32 rows per
+// instruction: with the pitch c = 200 (8 banks mod 32) rows r and r + 4 meet in a bank and half the banks idle; with
+// c + 4 (12 mod 32) eight consecutive rows cover all 32 banks exactly once.
+__host__ __device__ constexpr int raw_pitch(int c) { return c + 4; }
+
 template <int KS>
 inline size_t lds_bytes(int c) {
     const size_t sweep = 2 * (size_t)tile_bytes<KS>() + 4 * (size_t)EX_BYTES;
-    const size_t prologue = (size_t)tile_bytes<KS>() + (size_t)NG * 32 * c * 4;
+    const size_t prologue = (size_t)tile_bytes<KS>() + (size_t)NG * 32 * raw_pitch(c) * 4;
     return MISC_BYTES + (sweep > prologue ? sweep : prologue);
 }
 
@@ -120,11 +125,46 @@ __device__ __forceinline__ void load_raw(const float *__restrict__ O, int N, int
         const int pc = i * 512 + t;
         x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)pc * 16u, 0, 0);
     }
+    // piece pc = row * (c/4) + col  ->  LDS piece row * (c/4 + 1) + col = pc + row (raw_pitch).  row = pc / (c/4) through
+    // a float reciprocal: (pc + 0.5) / (c/4) is at least 0.5 / 52 away from an integer and pc < 2^14, so the rounding of
+    // the product cannot cross one.
+    // (the addresses are computed while the loads are in flight, not behind each wait)
+    const float inv_c4 = 1.0f / (float)(c / 4);
+    int at[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int pc = i * 512 + t;
-        if (pc < pieces) reinterpret_cast<u32x4 *>(raw)[pc] = x[i];
+        at[i] = pc < pieces ? pc + (int)(((float)pc + 0.5f) * inv_c4) : -1;
+        asm volatile("" : "+v"(at[i]));          // (materialised here: hipcc otherwise sinks it behind the wait)
     }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (at[i] >= 0) reinterpret_cast<u32x4 *>(raw)[at[i]] = x[i];
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// eight scaled values -> the hi and lo fp16 fragments (hi = RNE(y), lo = RNE(y - hi): y - hi is exact in fp32, so the
+// fused subtract-and-round of v_fma_mix gives the bits of the two-step form).  16 instructions per k-step: the multiply
+// and the first rounding on pairs (v_pk_mul_f32, gfx950's v_cvt_pk_f16_f32), one v_fma_mixlo/hi_f16 per lo element
+// (asm: left to itself hipcc vectorises the subtraction into v_cvt_f32_f16 x2 + v_pk_add + v_cvt_pk, 28 per k-step).
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, float up, bool ka, bool kb, f16x8 &hi, f16x8 &lo) {
+    const f32x2 u2 = {up, up};
+    f32x2 y[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
+    union { f16x2 h2[4]; f16x8 h8; unsigned u[4]; } H, Lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        y[j] = ((j < 2) ? ka : kb) ? y[j] * u2 : f32x2{0.f, 0.f};
+        H.h2[j] = __builtin_convertvector(y[j], f16x2);
+        unsigned l;
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(y[j][0]), "v"(H.u[j]));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(y[j][1]), "v"(H.u[j]));
+        Lo.u[j] = l;
+    }
+    hi = H.h8;
+    lo = Lo.h8;
 }
 
 // One row of the raw set -> hi/lo fp16 B fragments of k-steps [K0, K1) and the row's unscale factor.
@@ -133,7 +173,7 @@ template <int KS, int K0, int K1>
 __device__ __forceinline__ float convert_row(const unsigned char *raw, int row, int c, int h, f16x8 *Bh, f16x8 *Bl) {
     // (the offsets go through an empty asm: otherwise the loop-invariant fragment addresses are hoisted out
     // of the sweep loop and stay live across the MFMA chains)
-    int row_off = row * c, h8 = 8 * h;
+    int row_off = row * raw_pitch(c), h8 = 8 * h;
     asm volatile("" : "+v"(row_off), "+v"(h8));
     const float *lrow = reinterpret_cast<const float *>(raw) + row_off;
     float mx = 0.f;
@@ -167,17 +207,7 @@ __device__ __forceinline__ float convert_row(const unsigned char *raw, int row, 
         const int sh = rtk_pack_shift(mx);
         const float up = ldexpf(1.0f, sh);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float y0 = rw[2 * ks][q] * up, y1 = rw[2 * ks + 1][q] * up;
-                const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
-                Bh[ks][q] = h0;
-                Bh[ks][4 + q] = h1;
-                Bl[ks][q] = (_Float16)(y0 - (float)h0);
-                Bl[ks][4 + q] = (_Float16)(y1 - (float)h1);
-            }
-        }
+        for (int ks = 0; ks < KS; ++ks) split8(rw[2 * ks], rw[2 * ks + 1], up, true, true, Bh[ks], Bl[ks]);
         return ldexpf(1.0f, -sh);
     } else {
         static_assert(K1 - K0 == KS, "whole rows only: a k-range goes through convert_range");
@@ -189,7 +219,7 @@ __device__ __forceinline__ float convert_row(const unsigned char *raw, int row, 
 // find the maximum of the fifth group's rows while the M waves convert their own groups)
 template <int KS, int K0, int K1>
 __device__ __forceinline__ void convert_range(const unsigned char *raw, int row, int c, int h, float up, f16x8 *Bh, f16x8 *Bl) {
-    int row_off = row * c, h8 = 8 * h;
+    int row_off = row * raw_pitch(c), h8 = 8 * h;
     asm volatile("" : "+v"(row_off), "+v"(h8));
     const float *lrow = reinterpret_cast<const float *>(raw) + row_off;
     f32x4 rw[2 * (K1 - K0) + 1];
@@ -204,15 +234,7 @@ __device__ __forceinline__ void convert_range(const unsigned char *raw, int row,
     for (int ks = K0; ks < K1; ++ks) {
         const int k = 16 * ks + h8;
         const bool last = ks + 1 == KS;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float y0 = (!last || k + 4 <= c) ? rw[2 * (ks - K0)][q] * up : 0.f, y1 = (!last || k + 8 <= c) ? rw[2 * (ks - K0) + 1][q] * up : 0.f;
-            const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
-            Bh[ks - K0][q] = h0;
-            Bh[ks - K0][4 + q] = h1;
-            Bl[ks - K0][q] = (_Float16)(y0 - (float)h0);
-            Bl[ks - K0][4 + q] = (_Float16)(y1 - (float)h1);
-        }
+        split8(rw[2 * (ks - K0)], rw[2 * (ks - K0) + 1], up, !last || k + 4 <= c, !last || k + 8 <= c, Bh[ks - K0], Bl[ks - K0]);
     }
 }
 
@@ -236,10 +258,18 @@ struct LdsMap {
     }
 };
 
+// where an M wave stores its own group's scores of the LAST query tile itself (the drain)
+struct MOut {
+    float *out;
+    int64_t ld_out;
+    int B, nts;
+    unsigned voff;           // byte offset of (row 4h, this lane's column) in a tile's 32 output rows, or out of range
+};
+
 // ---- M role: the sweep over the query tiles with the set's fragments in registers --------------------------
 template <int KS, int W4, int SIGMOID, bool EXTRA>
 __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, const f16x8 (&Bh)[KS], const f16x8 (&Bl)[KS],
-                                        const f16x8 *Sh, const f16x8 *Sl, float us_o, bool tl_on, int &tl_n) {
+                                        const f16x8 *Sh, const f16x8 *Sl, float us_o, const MOut &mo, bool tl_on, int &tl_n) {
 #ifndef RTK_CG_PF
 #define RTK_CG_PF 3
 #endif
@@ -264,9 +294,13 @@ __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, cons
     // CHAIN (tile i exists) and PIECES (tile i-1 exists) are compile-time too: the steady-state loop below has
     // no branch in it.  (With `if (i < cnt)` / `if (i > 0)` inside one body the accumulators met at control-flow
     // joins and hipcc moved them between register sets: ~50 v_mov per tile-step in one of the two bodies.)
+    // DIRECT (the last tile, no chain left to hide under): the probabilities stay in the accumulator and the wave
+    // stores them itself -- the helper waves are storing tile cnt-2 and the fifth group meanwhile, and the launch ends
+    // one tile-step earlier than with a hand-over through LDS.
     auto iteration = [&](auto par_c, auto chain_c, auto pieces_c, int i, f32x16 &accC, f32x16 &accP) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool chain = decltype(chain_c)::value, pieces = decltype(pieces_c)::value;
+        constexpr bool direct = !chain && pieces;
         f32x4 *exw = reinterpret_cast<f32x4 *>(L.exo + (PAR ^ 1) * EX_BYTES + W4 * 4096);   // own slot of tile i-1
         f32x4 *exs = reinterpret_cast<f32x4 *>(L.exp5 + PAR * EX_BYTES + W4 * 4096);        // partial slot of tile i
         const float *rfp = reinterpret_cast<const float *>(L.hdr + ((i + 2) % 3) * 128) + 4 * h;  // row factors of tile i-1
@@ -292,13 +326,18 @@ __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, cons
                     ee = __builtin_amdgcn_exp2f(accP[e] * rfq[eg & 1][e & 3] * kfac);
                 } else {
                     accP[e] = __builtin_amdgcn_rcpf(1.0f + ee);
-                    if ((e & 3) == 3) exw[eg * 64 + lane] = f32x4{accP[e - 3], accP[e - 2], accP[e - 1], accP[e]};
+                    if ((e & 3) == 3 && !direct) exw[eg * 64 + lane] = f32x4{accP[e - 3], accP[e - 2], accP[e - 1], accP[e]};
                 }
             } else if ((p & 7) == 0) {               // logits / exact logistic: unscale only, 4 values per piece
                 f32x4 z;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) z[q] = accP[4 * eg + q] * rfq[eg & 1][q] * kfac;
-                exw[eg * 64 + lane] = z;
+                if (direct) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) accP[4 * eg + q] = (SIGMOID == 1) ? rtk_sigmoid(z[q]) : z[q];
+                } else {
+                    exw[eg * 64 + lane] = z;
+                }
             }
         };
         if (pieces) rfq[0] = *reinterpret_cast<const f32x4 *>(rfp);
@@ -359,6 +398,22 @@ __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, cons
         } else if constexpr (pieces) {           // drain: hand over the last tile
 #pragma unroll
             for (int gg = 0; gg < 32; ++gg) gap(gg + ((EXTRA && gg >= PW0) ? 4 : 0));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                mo.out + (int64_t)(i - 1) * 32 * mo.ld_out, 0, (unsigned)(min(32, mo.B - (i - 1) * 32) * mo.ld_out * 4), 0x00020000);
+            const unsigned ld4 = (unsigned)(mo.ld_out * 4);
+            // element e: row (e & 3) + 8 (e >> 2) + 4h.  (Through a scalar copy: __builtin_bit_cast applied to an
+            // ext-vector ELEMENT reads element 0 with this hipcc -- every store then carried accP[0].)
+            auto put = [&](auto aux_c) {
+                unsigned off = mo.voff;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pe = accP[e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pe), rs, off, 0, decltype(aux_c)::value);
+                    off += ((e & 3) == 3) ? 5u * ld4 : ld4;
+                }
+            };
+            if (mo.nts) put(std::integral_constant<int, 2>{});
+            else put(std::integral_constant<int, 0>{});
         }
         RTK_CG_TL(0, 6);
         __syncthreads();
@@ -377,15 +432,14 @@ __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, cons
     if (i < cnt) {                                                // cnt even: one more chain, its result in accB
         iteration(P1{}, T{}, T{}, i, accB, accA);
         iteration(P0{}, F{}, T{}, i + 1, accA, accB);
-        iteration(P1{}, F{}, F{}, i + 2, accB, accA);
     } else {                                                      // cnt odd: the last tile is in accA
         iteration(P1{}, F{}, T{}, i, accB, accA);
-        iteration(P0{}, F{}, F{}, i + 1, accA, accB);
     }
 }
 
 template <int KS, int W4, int SIGMOID>
-__device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__ O, const LdsMap &L, int lane, int t) {
+__device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__ O, float *__restrict__ out,
+                                       const LdsMap &L, int lane, int t, int nts) {
     constexpr int S0 = s_begin(KS, W4), S1 = s_end(KS, W4), NS = S1 - S0;
     const int r = lane & 31, h = lane >> 5, c = geo.c;
     const bool tl_on = W4 == 0 && lane == 0;
@@ -408,12 +462,18 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
         RTK_CG_TL(0, 3);
         __syncthreads();                             // S2: query tile 0 staged, the raw region is free
         RTK_CG_TL(0, 4);
+        MOut mo;
+        mo.out = out; mo.ld_out = geo.ld_out; mo.B = geo.B; mo.nts = nts;
+        {
+            const int j = (gb + W4) * 32 + r;
+            mo.voff = (own && j < geo.N) ? (unsigned)(4 * h * geo.ld_out * 4) + (unsigned)j * 4u : 0x80000000u;
+        }
         if (!own) {
-            for (int i = 0; i < geo.n_mt + 2; ++i) __syncthreads();
+            for (int i = 0; i < geo.n_mt + 1; ++i) __syncthreads();
         } else if (n_g == NG) {
-            m_sweep<KS, W4, SIGMOID, true>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, tl_on, tl_n);
+            m_sweep<KS, W4, SIGMOID, true>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, mo, tl_on, tl_n);
         } else {
-            m_sweep<KS, W4, SIGMOID, false>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, tl_on, tl_n);
+            m_sweep<KS, W4, SIGMOID, false>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, mo, tl_on, tl_n);
         }
     }
     RTK_CG_TLR(0, 13);
@@ -443,7 +503,7 @@ __device__ __forceinline__ void store_five(const float (&p5)[4], __amdgpu_buffer
 // S1b, while the M waves convert their own groups): eight lanes per row, 16-B pieces
 __device__ __forceinline__ void fifth_row_scales(const LdsMap &L, int c, int ht) {
     const int row = ht >> 3, sub = ht & 7;
-    const float *lrow = reinterpret_cast<const float *>(L.raw) + (4 * 32 + row) * c;
+    const float *lrow = reinterpret_cast<const float *>(L.raw) + (4 * 32 + row) * raw_pitch(c);
     float mx = 0.f;
     for (int p4 = sub; p4 * 4 < c; p4 += 8) {
         const f32x4 x = *reinterpret_cast<const f32x4 *>(lrow + 4 * p4);
@@ -524,7 +584,7 @@ __device__ __forceinline__ void s_role(const Geo &geo, const unsigned char *__re
         }
         float k5 = five ? L.uso5[r] : 0.f;
         if (SIGMOID == 2) k5 *= -1.4426950408889634f;
-        for (int i = 0; i < cnt + 2; ++i) {
+        for (int i = 0; i < cnt + 1; ++i) {              // (the own groups of the last tile: stored by the M waves)
             // Everything this wave reads from LDS in an iteration is requested in one batch (one LDS round trip: a
             // few hundred cycles under the M waves' fragment reads), then the stores go out back to back -- the
             // score stores are the resource that paces a tile-step (84 MB at the chip's write rate are ~1.8k cycles
@@ -628,7 +688,7 @@ __device__ __forceinline__ void l_role(const Geo &geo, const unsigned char *__re
         if (n_g == NG) fifth_row_scales(L, c, ht);
         __syncthreads();                             // S1b
         __syncthreads();                             // S2
-        for (int i = 0; i < cnt + 2; ++i) {
+        for (int i = 0; i < cnt + 1; ++i) {
             // tile i+1 was requested an iteration ago (tile 1: in the prologue); buffer (i+1) & 1 held tile i-1, which
             // the M waves left at the last barrier.  Tile i+2 is requested right behind the write, into the same
             // registers: its L2 round trip has a whole tile-step.
@@ -659,10 +719,10 @@ __global__ __launch_bounds__(512, 2) void score_cg_kernel(
         else if (pr == 2) __builtin_amdgcn_s_setprio(2);
         else if (pr == 3) __builtin_amdgcn_s_setprio(3);
     }
-    if (uwave == 0) m_role<KS, 0, SIGMOID>(geo, O, L, lane, t);
-    else if (uwave == 1) m_role<KS, 1, SIGMOID>(geo, O, L, lane, t);
-    else if (uwave == 2) m_role<KS, 2, SIGMOID>(geo, O, L, lane, t);
-    else if (uwave == 3) m_role<KS, 3, SIGMOID>(geo, O, L, lane, t);
+    if (uwave == 0) m_role<KS, 0, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
+    else if (uwave == 1) m_role<KS, 1, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
+    else if (uwave == 2) m_role<KS, 2, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
+    else if (uwave == 3) m_role<KS, 3, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
     else if (uwave == 4) s_role<KS, SIGMOID, 0>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
     else if (uwave == 5) s_role<KS, SIGMOID, 1>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
     else if (uwave == 6) s_role<KS, SIGMOID, 2>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
