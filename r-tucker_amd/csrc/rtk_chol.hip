@@ -32,7 +32,7 @@ constexpr int GRP = 2;        // global read-modify-writes in flight per thread 
 // Lo / Ti are the output buffers, used as working storage (lower triangles) until the final transposition.
 __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__ S, int k, int equil, double shift_diag,
                                                       double shift_trace, double *__restrict__ Lo,
-                                                      double *__restrict__ Ti) {
+                                                      double *__restrict__ Ti, int tune) {
     __shared__ double dd[NB][NB + 1];        // diagonal block of A -> L11
     __shared__ double ti[NB][NB + 1];        // identity -> T11 = L11^-1
     __shared__ double pan[KMAX][NB + 1];     // panel L[i, j-block] for i below the block
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
         dd[r][cc] = (r < w && cc <= r) ? Lo[(size_t)(j0 + r) * k + j0 + cc] : 0.0;
         ti[r][cc] = (r == cc) ? 1.0 : 0.0;
         __syncthreads();
-        for (int c = 0; c < w; ++c) {
+        for (int c = 0; c < ((tune & 1) ? 0 : w); ++c) {
             __syncthreads();                 // the previous column's updates are visible
             const double floor_ = fmax(1e-14 * fabs(dg[j0 + c]), 0.5 * shift) + 1e-300;
             const double piv = sqrt(fmax(dd[c][c], floor_));     // dd[c][c] itself is left alone (pv holds L[c][c])
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
         // L11 out; rows of the inverse: B[j-block, 0:left] <- T11 * B[j-block, 0:left]  (their old diagonal
         // block is the identity, columns < j0 hold the updates of the earlier steps)
         if (r < w && cc <= r) Lo[(size_t)(j0 + r) * k + j0 + cc] = (cc == r) ? pv[r] : dd[r][cc];
-        for (int e = t; e < left * NB; e += NT) {   // stage the old rows: bj[c][m] = B[j0 + m][c]
+        for (int e = t; e < ((tune & 2) ? 0 : left * NB); e += NT) {   // stage the old rows: bj[c][m] = B[j0 + m][c]
             const int m = e / left, c = e - m * left;
             bj[c][m] = (m < w) ? Ti[(size_t)(j0 + m) * k + c] : 0.0;
         }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
             }
         }
         // --- B) panel: L[i, j-block] = A[i, j-block] * T11^T   (i below the block)
-        for (int e = t; e < below * NB; e += NT) {
+        for (int e = t; e < ((tune & 4) ? 0 : below * NB); e += NT) {
             const int i = e >> 5, c = e & 31;
             double s = 0.0;
             if (c < w) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
         // Read-modify-writes of global memory in groups of eight: the loads of a group are in flight together
         // (one after the other, each waiting for the previous store, they were 80 % of the kernel).
         // A[i, c2] -= sum_m pan[i][m] pan[c2][m],  j0 + w <= c2 <= i
-        for (int e0 = t; e0 < below * below; e0 += GRP * NT) {
+        for (int e0 = t; e0 < ((tune & 8) ? 0 : below * below); e0 += GRP * NT) {
             double old[GRP], s8[GRP];
             size_t at[GRP];
             bool on[GRP];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NT) void chol_inv_kernel(const double *__restrict__
                 if (on[u]) Lo[at[u]] = old[u] - s8[u];
         }
         // B[i, c] -= sum_m pan[i][m] * B[j0 + m, c],  c < left
-        for (int e0 = t; e0 < below * left; e0 += GRP * NT) {
+        for (int e0 = t; e0 < ((tune & 16) ? 0 : below * left); e0 += GRP * NT) {
             double old[GRP], s8[GRP];
             size_t at[GRP];
             bool on[GRP];
@@ -215,7 +215,8 @@ extern "C" int rtk_gram_factor_f64(const void *S, int64_t batch, int k, int equi
     RTK_REQUIRE(k > 0 && k <= KMAX, RTK_ERR_UNSUPPORTED, "rtk_gram_factor_f64: k=%d not in [1, %d]", k, KMAX);
     RTK_REQUIRE(S != R_out && S != X_out && R_out != X_out, RTK_ERR_BAD_ARG, "rtk_gram_factor_f64: buffers must be distinct");
     RTK_REQUIRE(shift_diag >= 0.0 && shift_trace >= 0.0, RTK_ERR_BAD_ARG, "rtk_gram_factor_f64: shifts must be >= 0");
+    static const int tune = getenv("RTK_CHOL_TUNE") ? atoi(getenv("RTK_CHOL_TUNE")) : 0;   // timing ablations (wrong results)
     hipLaunchKernelGGL(chol_inv_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, (const double *)S, k,
-                       equilibrate ? 1 : 0, shift_diag, shift_trace, (double *)R_out, (double *)X_out);
+                       equilibrate ? 1 : 0, shift_diag, shift_trace, (double *)R_out, (double *)X_out, tune);
     return rtk_check_launch("rtk_gram_factor_f64");
 }

@@ -32,10 +32,15 @@
 //                   waits by hand -- an LDS-DMA piece costs the issuing wave ~150 cycles here, 1.1k per tile-step.)
 // One barrier per tile-step.  Columns of the four own groups are computed by the same instruction sequence as
 // in the ws kernel (bit-identical scores); columns of a fifth group are the sum of four K-range chains.
+// Prologue (two barriers): every M wave requests its rows of O straight into registers in B-fragment order (26 + 6..8
+// loads per lane, first thing in the kernel; no pass through LDS), the four partial row maxima of the fifth group meet
+// in LDS (P1), both conversions run in place (fp32 pieces -> hi / lo fp16 fragments: v_pk_mul_f32, v_cvt_pk_f16_f32,
+// v_fma_mix), the helper waves stage query tile 0 meanwhile (P2): first MFMA at 5.3k cycles (10.1k with the set staged
+// through LDS by all waves, the round's first form).  Drain: the M waves store the own groups of the LAST tile themselves
+// while the S waves store tile cnt-2 and the fifth group, so the launch ends one tile-step earlier.
 //
-// LDS (KS = 13): [misc 640 B: row-factor ring 3 x 128 B, fifth group's column factors 2 x 128 B]
-//                [query tile 0][ X: raw O set (<= 160 rows x c fp32) during the prologue;
-//                                  then query tile 1 | own exchange 2 x 16 KiB | partial sums 2 x 16 KiB ]
+// LDS (KS = 13): [misc 1 KiB: row-factor ring 3 x 128 B, fifth group's column factors 128 B, partial maxima 512 B]
+//                [query tile 0][query tile 1][own exchange 2 x 16 KiB][partial sums 2 x 16 KiB]      = 119 KiB
 #pragma once
 #include "rtk_common.h"
 #include "rtk_pack.h"
@@ -71,22 +76,13 @@ static __device__ unsigned long long g_cg_tl[256 * 2 * 64];
 
 constexpr int NG = 5;                       // groups per set (4 in registers + 1 split along K)
 constexpr int EX_BYTES = 4 * 4 * 64 * 16;   // one exchange buffer: 4 waves x 16 accumulator regs x 64 lanes x f32
-constexpr int MISC_BYTES = 640;
+constexpr int MISC_BYTES = 1024;
 
 template <int KS>
 __host__ __device__ constexpr int tile_bytes() { return RTK_PACK_HDR + 2 * KS * 1024; }
 
-// Row pitch (floats) of the raw set in LDS: c plus four.  A lane of the conversion reads 16 B of "its" row, 32 rows per
-// instruction: with the pitch c = 200 (8 banks mod 32) rows r and r + 4 meet in a bank and half the banks idle; with
-// c + 4 (12 mod 32) eight consecutive rows cover all 32 banks exactly once.
-__host__ __device__ constexpr int raw_pitch(int c) { return c + 4; }
-
 template <int KS>
-inline size_t lds_bytes(int c) {
-    const size_t sweep = 2 * (size_t)tile_bytes<KS>() + 4 * (size_t)EX_BYTES;
-    const size_t prologue = (size_t)tile_bytes<KS>() + (size_t)NG * 32 * raw_pitch(c) * 4;
-    return MISC_BYTES + (sweep > prologue ? sweep : prologue);
-}
+inline size_t lds_bytes(int) { return MISC_BYTES + 2 * (size_t)tile_bytes<KS>() + 4 * (size_t)EX_BYTES; }
 
 // shared k-step range of M wave w (the fifth group's chain cut in four): ceil(KS*w/4) .. ceil(KS*(w+1)/4)
 __host__ __device__ constexpr int s_begin(int KS, int w) { return (KS * w + 3) / 4; }
@@ -102,45 +98,6 @@ struct Geo {
         n_g = (int)(G * (u + 1) / U) - gb;
     }
 };
-
-// All 512 threads: the set's rows of O (contiguous in memory, c % 4 == 0) -> LDS, 16-B pieces, all loads of
-// a thread in flight together; rows past N are zero-filled (their columns are never stored).
-template <int KS>
-__device__ __forceinline__ void load_raw(const float *__restrict__ O, int N, int c, int gb, int n_g,
-                                         unsigned char *raw, int t) {
-    // (through an empty asm: the per-thread piece addresses are otherwise computed once, ahead of the loop over
-    // the sets, and kept -- or spilled -- across the sweep)
-    asm volatile("" : "+v"(t));
-    constexpr int NCH = (NG * 32 * 16 * KS / 4 + 511) / 512;       // 16-B pieces per thread at c = 16*KS
-    const int64_t row0 = (int64_t)gb * 32;
-    const int pieces = n_g * 8 * c;                                  // 32 rows x c floats / 4 per group
-    const int valid = (int)max((int64_t)0, min((int64_t)n_g * 32, (int64_t)N - row0)) * (c / 4);
-    // through a buffer descriptor over the valid rows: a piece past them reads as zero, no branch around
-    // any load (a conditional load makes hipcc wait for the previous one: 17 dependent round trips)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(O + row0 * c), 0, (unsigned)valid * 16u, 0x00020000);
-    u32x4 x[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int pc = i * 512 + t;
-        x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)pc * 16u, 0, 0);
-    }
-    // piece pc = row * (c/4) + col  ->  LDS piece row * (c/4 + 1) + col = pc + row (raw_pitch).  row = pc / (c/4) through
-    // a float reciprocal: (pc + 0.5) / (c/4) is at least 0.5 / 52 away from an integer and pc < 2^14, so the rounding of
-    // the product cannot cross one.
-    // (the addresses are computed while the loads are in flight, not behind each wait)
-    const float inv_c4 = 1.0f / (float)(c / 4);
-    int at[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int pc = i * 512 + t;
-        at[i] = pc < pieces ? pc + (int)(((float)pc + 0.5f) * inv_c4) : -1;
-        asm volatile("" : "+v"(at[i]));          // (materialised here: hipcc otherwise sinks it behind the wait)
-    }
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-        if (at[i] >= 0) reinterpret_cast<u32x4 *>(raw)[at[i]] = x[i];
-}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -167,92 +124,55 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, float up, b
     lo = Lo.h8;
 }
 
-// One row of the raw set -> hi/lo fp16 B fragments of k-steps [K0, K1) and the row's unscale factor.
-// The scale comes from the maximum over the WHOLE row (all k-steps), whatever range is converted.
+// The set's rows of O go from memory STRAIGHT into the registers of the wave that converts them, in B-fragment order
+// (lane (r, h) of M wave w: row 32 w + r, the sixteen bytes at k = 16 ks + 8 h and the next sixteen, every k-step) --
+// 26 loads per lane issued first thing in the kernel, no pass through LDS, no barrier in front of the conversion.
+// (Round 4's first form staged the whole set in LDS with all 512 threads and converted from there: the 27 ds_reads of a
+// lane, the LDS write pass and the barrier between them put the first MFMA at 10.1k cycles; this form: see DESIGN.md.)
+// Rows past N read as zero through the buffer descriptor's range (their columns are never stored); only the LAST k-step
+// can reach past column c, its pieces are masked by hand (the next row's data lies there, not the end of the buffer).
 template <int KS, int K0, int K1>
-__device__ __forceinline__ float convert_row(const unsigned char *raw, int row, int c, int h, f16x8 *Bh, f16x8 *Bl) {
-    // (the offsets go through an empty asm: otherwise the loop-invariant fragment addresses are hoisted out
-    // of the sweep loop and stay live across the MFMA chains)
-    int row_off = row * raw_pitch(c), h8 = 8 * h;
-    asm volatile("" : "+v"(row_off), "+v"(h8));
-    const float *lrow = reinterpret_cast<const float *>(raw) + row_off;
-    float mx = 0.f;
-    if constexpr (K1 - K0 == KS) {
-        // whole row: read once, keep in registers for the maximum and the conversion.  KS = ceil(c / 16), so only the
-        // LAST k-step can reach past column c: the others need no mask (the masks were a third of this pass).
-        f32x4 rw[2 * KS];
+__device__ __forceinline__ void load_fragments_raw(__amdgpu_buffer_rsrc_t rs, unsigned n_bytes, int row, int c, int h, f32x4 *rw) {
+    // ONE address register: the k-step's 64 bytes and the second piece's 16 ride in the scalar / immediate offset.  A
+    // masked piece is requested at the end of the buffer: it reads as zero, and no branch surrounds a load.
+    const unsigned base = (unsigned)(row * c + 8 * h) * 4u;
+    const int k_last = 16 * (KS - 1) + 8 * h;
+    const unsigned base_a = (k_last + 4 <= c) ? base : n_bytes, base_b = (k_last + 8 <= c) ? base : n_bytes;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = 16 * ks + h8;                  // k = 16*ks + 8*h + q  (B-operand map of 32x32x16)
-            if (ks + 1 < KS) {
-                rw[2 * ks] = *reinterpret_cast<const f32x4 *>(lrow + k);
-                rw[2 * ks + 1] = *reinterpret_cast<const f32x4 *>(lrow + k + 4);
-            } else {
-                rw[2 * ks] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 4 <= c) ? k : 0));
-                rw[2 * ks + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((k + 8 <= c) ? k + 4 : 0));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!(k + 4 <= c)) rw[2 * ks][q] = 0.f;
-                    if (!(k + 8 <= c)) rw[2 * ks + 1][q] = 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)      // one v_max3_f32 with |.| modifiers per pair
-                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mx) : "v"(rw[2 * ks][q]), "v"(rw[2 * ks + 1][q]));
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const int sh = rtk_pack_shift(mx);
-        const float up = ldexpf(1.0f, sh);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) split8(rw[2 * ks], rw[2 * ks + 1], up, true, true, Bh[ks], Bl[ks]);
-        return ldexpf(1.0f, -sh);
-    } else {
-        static_assert(K1 - K0 == KS, "whole rows only: a k-range goes through convert_range");
-        return 0.f;
+    for (int ks = K0; ks < K1; ++ks) {
+        const bool last = ks + 1 == KS;
+        rw[2 * (ks - K0)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, last ? base_a : base, 64 * ks, 0));
+        rw[2 * (ks - K0) + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, last ? base_b : base, 64 * ks + 16, 0));
     }
 }
 
-// k-steps [K0, K1) of one row -> hi/lo fp16 B fragments, with the row's scale `up` given (the helper waves
-// find the maximum of the fifth group's rows while the M waves convert their own groups)
-template <int KS, int K0, int K1>
-__device__ __forceinline__ void convert_range(const unsigned char *raw, int row, int c, int h, float up, f16x8 *Bh, f16x8 *Bl) {
-    int row_off = row * raw_pitch(c), h8 = 8 * h;
-    asm volatile("" : "+v"(row_off), "+v"(h8));
-    const float *lrow = reinterpret_cast<const float *>(raw) + row_off;
-    f32x4 rw[2 * (K1 - K0) + 1];
+// largest magnitude of NP pieces of a lane, both halves (h = 0, 1) of the row combined
+template <int NP>
+__device__ __forceinline__ float row_absmax(const f32x4 *rw) {
+    float mx = 0.f;
 #pragma unroll
-    for (int ks = K0; ks < K1; ++ks) {
-        const int k = 16 * ks + h8;
-        const bool last = ks + 1 == KS;              // (only the last k-step can reach past column c)
-        rw[2 * (ks - K0)] = *reinterpret_cast<const f32x4 *>(lrow + ((!last || k + 4 <= c) ? k : 0));
-        rw[2 * (ks - K0) + 1] = *reinterpret_cast<const f32x4 *>(lrow + ((!last || k + 8 <= c) ? k + 4 : 0));
-    }
+    for (int i = 0; i + 1 < NP; i += 2) {
 #pragma unroll
-    for (int ks = K0; ks < K1; ++ks) {
-        const int k = 16 * ks + h8;
-        const bool last = ks + 1 == KS;
-        split8(rw[2 * (ks - K0)], rw[2 * (ks - K0) + 1], up, !last || k + 4 <= c, !last || k + 8 <= c, Bh[ks - K0], Bl[ks - K0]);
+        for (int q = 0; q < 4; ++q)          // one v_max3_f32 with |.| modifiers per pair
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mx) : "v"(rw[i][q]), "v"(rw[i + 1][q]));
     }
+    return fmaxf(mx, __shfl_xor(mx, 32));
 }
 
 struct LdsMap {
     unsigned char *hdr;      // 3 x 128 B: row factors of the query tiles t % 3 (they outlive the tile's buffer)
-    float *uso5, *up5;       // 2 x 32 floats: unscale / scale factors (powers of two) of the fifth group's columns
+    float *uso5;             // 32 floats: unscale factors (powers of two) of the fifth group's columns
+    float *pmax;             // 4 x 32 floats: the fifth group's row maxima over each M wave's k-range
     unsigned char *stg0, *stg1;   // query tile t in buffer t & 1
-    unsigned char *raw;      // prologue: the set's rows of O (over buffer 1 and the exchange)
     unsigned char *exo;      // 2 x EX_BYTES: own accumulators (probabilities) of tile t & 1
     unsigned char *exp5;     // 2 x EX_BYTES: the four partial accumulators of the fifth group, tile t & 1
     template <int KS>
     __device__ __forceinline__ void init(unsigned char *lds) {
         hdr = lds;
         uso5 = reinterpret_cast<float *>(lds + 384);
-        up5 = reinterpret_cast<float *>(lds + 512);
+        pmax = reinterpret_cast<float *>(lds + 512);
         stg0 = lds + MISC_BYTES;
-        raw = stg0 + tile_bytes<KS>();
-        stg1 = raw;
+        stg1 = stg0 + tile_bytes<KS>();
         exo = stg1 + tile_bytes<KS>();
         exp5 = exo + 2 * EX_BYTES;
     }
@@ -268,8 +188,8 @@ struct MOut {
 
 // ---- M role: the sweep over the query tiles with the set's fragments in registers --------------------------
 template <int KS, int W4, int SIGMOID, bool EXTRA>
-__device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, const f16x8 (&Bh)[KS], const f16x8 (&Bl)[KS],
-                                        const f16x8 *Sh, const f16x8 *Sl, float us_o, const MOut &mo, bool tl_on, int &tl_n) {
+__device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, const f16x8 (&BF)[2 * KS],
+                                        const f16x8 *SF, float us_o, const MOut &mo, bool tl_on, int &tl_n) {
 #ifndef RTK_CG_PF
 #define RTK_CG_PF 3
 #endif
@@ -362,32 +282,32 @@ __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, cons
                 const bool sh = EXTRA && ks >= S0 && ks < S1;
                 // sched_barrier(0) pins the written order MFMA / piece / MFMA / piece (see the ws kernel)
                 __builtin_amdgcn_sched_barrier(0);
-                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[ks], ks == 0 ? zero : accC, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BF[2 * ks], ks == 0 ? zero : accC, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 gap(g++);
                 __builtin_amdgcn_sched_barrier(0);
                 if (sh) {
-                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Sh[ks - S0], ks == S0 ? zero : accS, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, SF[2 * (ks - S0)], ks == S0 ? zero : accS, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     gap(g++);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[ks], accC, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BF[2 * ks + 1], accC, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 gap(g++);
                 __builtin_amdgcn_sched_barrier(0);
                 if (sh) {
-                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Sl[ks - S0], accS, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, SF[2 * (ks - S0) + 1], accS, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     gap(g++);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[ks], accC, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, BF[2 * ks], accC, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 gap(g++);
                 __builtin_amdgcn_sched_barrier(0);
                 if (sh) {
-                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Sh[ks - S0], accS, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, SF[2 * (ks - S0)], accS, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     gap(g++);
                     __builtin_amdgcn_sched_barrier(0);
@@ -449,18 +369,50 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
         int gb, n_g;
         geo.set(u, gb, n_g);
         RTK_CG_TL(0, 1);
-        load_raw<KS>(O, geo.N, c, gb, n_g, L.raw, t);
-        __syncthreads();                             // S1: the raw set is in LDS
-        RTK_CG_TL(0, 2);
         const bool own = W4 < n_g;
-        f16x8 Bh[KS], Bl[KS], Sh[NS > 0 ? NS : 1], Sl[NS > 0 ? NS : 1];
+        // BF[2 ks] / BF[2 ks + 1]: the raw fp32 pieces of k-step ks until the conversion, its hi / lo fp16 fragments after it
+        // -- the same sixteen bytes per lane, converted IN PLACE (with the fragments in arrays of their own the allocator
+        // held both generations through the conversion: ~100 spills).  SF: the same for this wave's k-range of the fifth
+        // group (SF[2 j] / SF[2 j + 1] = Sh / Sl of k-step S0 + j).
+        constexpr int NSX = NS > 0 ? NS : 1;
+        f16x8 BF[2 * KS], SF[2 * NSX];
         float us_o = 0.f;
-        if (own) us_o = convert_row<KS, 0, KS>(L.raw, W4 * 32 + r, c, h, Bh, Bl);
-        RTK_CG_TL(0, 7);
-        __syncthreads();                             // S1b: the helper waves have the fifth group's row scales
-        if (n_g == NG) convert_range<KS, S0, S1>(L.raw, 4 * 32 + r, c, h, L.up5[r], Sh, Sl);
+        {
+            const int64_t row0 = (int64_t)gb * 32;
+            const int valid_rows = (int)max((int64_t)0, min((int64_t)n_g * 32, (int64_t)geo.N - row0));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(O + row0 * c), 0, (unsigned)valid_rows * (unsigned)c * 4u, 0x00020000);
+            const unsigned n_bytes = (unsigned)valid_rows * (unsigned)c * 4u;
+            if (NS > 0) load_fragments_raw<KS, S0, S1>(rs, n_bytes, 4 * 32 + r, c, h, reinterpret_cast<f32x4 *>(SF));
+            load_fragments_raw<KS, 0, KS>(rs, n_bytes, W4 * 32 + r, c, h, reinterpret_cast<f32x4 *>(BF));
+            // the fifth group's rows: this wave's k-range only -- the row maximum is the largest of the four waves' (a
+            // group the set does not have reads as zero).  Requested first, exchanged first: the barrier then sits under
+            // the own group's loads, and both conversions run behind it without another wait.
+            const float pm = NS > 0 ? row_absmax<2 * NSX>(reinterpret_cast<const f32x4 *>(SF)) : 0.f;
+            if (h == 0) L.pmax[W4 * 32 + r] = pm;
+            RTK_CG_TL(0, 2);
+            __syncthreads();                         // P1: the four partial maxima are in LDS
+            if (n_g == NG) {
+                const float m5 = fmaxf(fmaxf(L.pmax[r], L.pmax[32 + r]), fmaxf(L.pmax[64 + r], L.pmax[96 + r]));
+                const int sh5 = rtk_pack_shift(m5);
+                const float up5 = ldexpf(1.0f, sh5);
+#pragma unroll
+                for (int ks = 0; ks < NS; ++ks)
+                    split8(__builtin_bit_cast(f32x4, SF[2 * ks]), __builtin_bit_cast(f32x4, SF[2 * ks + 1]), up5, true, true, SF[2 * ks], SF[2 * ks + 1]);
+                if (W4 == 0 && h == 0) L.uso5[r] = ldexpf(1.0f, -sh5);
+            }
+            RTK_CG_TL(0, 7);
+            if (own) {
+                const int sh = rtk_pack_shift(row_absmax<2 * KS>(reinterpret_cast<const f32x4 *>(BF)));
+                const float up = ldexpf(1.0f, sh);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    split8(__builtin_bit_cast(f32x4, BF[2 * ks]), __builtin_bit_cast(f32x4, BF[2 * ks + 1]), up, true, true, BF[2 * ks], BF[2 * ks + 1]);
+                us_o = ldexpf(1.0f, -sh);
+            }
+        }
         RTK_CG_TL(0, 3);
-        __syncthreads();                             // S2: query tile 0 staged, the raw region is free
+        __syncthreads();                             // P2: query tile 0 staged, the fifth group's column factors written
         RTK_CG_TL(0, 4);
         MOut mo;
         mo.out = out; mo.ld_out = geo.ld_out; mo.B = geo.B; mo.nts = nts;
@@ -471,9 +423,9 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
         if (!own) {
             for (int i = 0; i < geo.n_mt + 1; ++i) __syncthreads();
         } else if (n_g == NG) {
-            m_sweep<KS, W4, SIGMOID, true>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, mo, tl_on, tl_n);
+            m_sweep<KS, W4, SIGMOID, true>(L, geo.n_mt, lane, BF, SF, us_o, mo, tl_on, tl_n);
         } else {
-            m_sweep<KS, W4, SIGMOID, false>(L, geo.n_mt, lane, Bh, Bl, Sh, Sl, us_o, mo, tl_on, tl_n);
+            m_sweep<KS, W4, SIGMOID, false>(L, geo.n_mt, lane, BF, SF, us_o, mo, tl_on, tl_n);
         }
     }
     RTK_CG_TLR(0, 13);
@@ -499,28 +451,7 @@ __device__ __forceinline__ void store_five(const float (&p5)[4], __amdgpu_buffer
     }
 }
 
-// the fifth group's row maxima -> power-of-two scale and its inverse (all 256 helper threads, between S1 and
-// S1b, while the M waves convert their own groups): eight lanes per row, 16-B pieces
-__device__ __forceinline__ void fifth_row_scales(const LdsMap &L, int c, int ht) {
-    const int row = ht >> 3, sub = ht & 7;
-    const float *lrow = reinterpret_cast<const float *>(L.raw) + (4 * 32 + row) * raw_pitch(c);
-    float mx = 0.f;
-    for (int p4 = sub; p4 * 4 < c; p4 += 8) {
-        const f32x4 x = *reinterpret_cast<const f32x4 *>(lrow + 4 * p4);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 1));
-    mx = fmaxf(mx, __shfl_xor(mx, 2));
-    mx = fmaxf(mx, __shfl_xor(mx, 4));
-    if (sub == 0) {
-        const int sh = rtk_pack_shift(mx);
-        L.up5[row] = ldexpf(1.0f, sh);
-        L.uso5[row] = ldexpf(1.0f, -sh);
-    }
-}
-
-// Prologue of all four helper waves: query tile 0 (256 threads, requested first: its L2 round trip runs beside the
-// raw set's loads) -> buffer 0 and row-factor slot 0, and their share of the raw set -> LDS.
+// Prologue of all four helper waves: query tile 0 (256 threads) -> buffer 0 and row-factor slot 0.
 template <int KS>
 __device__ __forceinline__ void h_prologue(const Geo &geo, const unsigned char *__restrict__ q_packed,
                                            const float *__restrict__ O, const LdsMap &L, int gb, int n_g, int t) {
@@ -535,7 +466,6 @@ __device__ __forceinline__ void h_prologue(const Geo &geo, const unsigned char *
         const int ch = i * 256 + ht;
         if (i + 1 < NLD || ch < CHUNKS) sreg[i] = src[ch];
     }
-    load_raw<KS>(O, geo.N, geo.c, gb, n_g, L.raw, t);
     u32x4 *dst = reinterpret_cast<u32x4 *>(L.stg0);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -554,7 +484,7 @@ __device__ __forceinline__ void s_role(const Geo &geo, const unsigned char *__re
                                        const float *__restrict__ O, float *__restrict__ out,
                                        const LdsMap &L, int lane, int t, int nts, int tune) {
     constexpr int NU = (20 - SW + 2) / 3;        // units of this wave
-    const int r = lane & 31, h = lane >> 5, c = geo.c, N = geo.N, B = geo.B, ht = t & 255;
+    const int r = lane & 31, h = lane >> 5, N = geo.N, B = geo.B;
     const int64_t ld_out = geo.ld_out;
     const unsigned ld4 = (unsigned)(ld_out * 4);
     const int cnt = geo.n_mt;
@@ -566,12 +496,9 @@ __device__ __forceinline__ void s_role(const Geo &geo, const unsigned char *__re
         RTK_CG_TL(1, 1);
         h_prologue<KS>(geo, q_packed, O, L, gb, n_g, t);
         RTK_CG_TL(1, 2);
-        __syncthreads();                             // S1
-        RTK_CG_TL(1, 3);
         const bool five = n_g == NG;
-        if (five) fifth_row_scales(L, c, ht);
-        __syncthreads();                             // S1b
-        __syncthreads();                             // S2
+        __syncthreads();                             // P1
+        __syncthreads();                             // P2
         RTK_CG_TL(1, 4);
         // byte offset of (row 4h, this lane's column of group g) in a tile's 32 output rows; past-the-end columns and
         // groups the set does not have get an offset the buffer range check drops
@@ -656,7 +583,6 @@ __device__ __forceinline__ void l_role(const Geo &geo, const unsigned char *__re
     constexpr int TILE_BYTES = tile_bytes<KS>();
     constexpr int CHUNKS = TILE_BYTES / 16;
     constexpr int NLD = (CHUNKS + 63) / 64;     // staging 16-B chunks per lane
-    const int c = geo.c, ht = t & 255;
     const int cnt = geo.n_mt;
     u32x4 sreg[NLD];
     // (through a buffer descriptor: ONE address register, the piece and tile offsets are scalar; a piece past the
@@ -684,10 +610,8 @@ __device__ __forceinline__ void l_role(const Geo &geo, const unsigned char *__re
         geo.set(u, gb, n_g);
         h_prologue<KS>(geo, q_packed, O, L, gb, n_g, t);
         if (cnt > 1 && !(tune & 32)) stage_load(1);  // in flight across the prologue's barriers
-        __syncthreads();                             // S1
-        if (n_g == NG) fifth_row_scales(L, c, ht);
-        __syncthreads();                             // S1b
-        __syncthreads();                             // S2
+        __syncthreads();                             // P1
+        __syncthreads();                             // P2
         for (int i = 0; i < cnt + 1; ++i) {
             // tile i+1 was requested an iteration ago (tile 1: in the prologue); buffer (i+1) & 1 held tile i-1, which
             // the M waves left at the last barrier.  Tile i+2 is requested right behind the write, into the same

@@ -56,7 +56,7 @@ tl = tl.reshape(256, 2, 64)
 code = (tl >> np.uint64(56)).astype(np.int64)
 tm = (tl & np.uint64((1 << 56) - 1)).astype(np.int64)
 print(f"event-bracketed launch (stamped build): {e0.elapsed_time(e1) * 1e3:.1f} us")
-NAMES = {0: {1: "start", 2: "S1 passed (raw set in LDS)", 7: "own group converted (before P1)", 3: "fifth range converted", 4: "S2 passed", 6: "chain + pieces done", 5: "barrier passed"},
+NAMES = {0: {1: "start", 2: "loads landed, partial maxima written", 7: "P1 passed, fifth range converted", 3: "own group converted", 4: "S2 passed", 6: "chain + pieces done", 5: "barrier passed"},
          1: {1: "start", 2: "query tile 0 written", 3: "S1 passed", 4: "S2 passed", 9: "DMA of tile i+2 issued", 10: "row factors copied", 11: "LDS reads requested", 8: "fifth group summed",
              6: "stores issued", 5: "barrier passed"}}
 BRIEF = os.environ.get("BRIEF") is not None
