@@ -101,19 +101,18 @@ struct Geo {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // eight scaled values -> the hi and lo fp16 fragments (hi = RNE(y), lo = RNE(y - hi): y - hi is exact in fp32, so the
 // fused subtract-and-round of v_fma_mix gives the bits of the two-step form).  16 instructions per k-step: the multiply
 // and the first rounding on pairs (v_pk_mul_f32, gfx950's v_cvt_pk_f16_f32), one v_fma_mixlo/hi_f16 per lo element
 // (asm: left to itself hipcc vectorises the subtraction into v_cvt_f32_f16 x2 + v_pk_add + v_cvt_pk, 28 per k-step).
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, float up, bool ka, bool kb, f16x8 &hi, f16x8 &lo) {
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, float up, f16x8 &hi, f16x8 &lo) {
     const f32x2 u2 = {up, up};
     f32x2 y[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
     union { f16x2 h2[4]; f16x8 h8; unsigned u[4]; } H, Lo;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        y[j] = ((j < 2) ? ka : kb) ? y[j] * u2 : f32x2{0.f, 0.f};
+        y[j] = y[j] * u2;
         H.h2[j] = __builtin_convertvector(y[j], f16x2);
         unsigned l;
         asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(y[j][0]), "v"(H.u[j]));
@@ -398,7 +397,7 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
                 const float up5 = ldexpf(1.0f, sh5);
 #pragma unroll
                 for (int ks = 0; ks < NS; ++ks)
-                    split8(__builtin_bit_cast(f32x4, SF[2 * ks]), __builtin_bit_cast(f32x4, SF[2 * ks + 1]), up5, true, true, SF[2 * ks], SF[2 * ks + 1]);
+                    split8(__builtin_bit_cast(f32x4, SF[2 * ks]), __builtin_bit_cast(f32x4, SF[2 * ks + 1]), up5, SF[2 * ks], SF[2 * ks + 1]);
                 if (W4 == 0 && h == 0) L.uso5[r] = ldexpf(1.0f, -sh5);
             }
             RTK_CG_TL(0, 7);
@@ -407,7 +406,7 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
                 const float up = ldexpf(1.0f, sh);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
-                    split8(__builtin_bit_cast(f32x4, BF[2 * ks]), __builtin_bit_cast(f32x4, BF[2 * ks + 1]), up, true, true, BF[2 * ks], BF[2 * ks + 1]);
+                    split8(__builtin_bit_cast(f32x4, BF[2 * ks]), __builtin_bit_cast(f32x4, BF[2 * ks + 1]), up, BF[2 * ks], BF[2 * ks + 1]);
                 us_o = ldexpf(1.0f, -sh);
             }
         }
@@ -432,15 +431,6 @@ __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__
 }
 
 // ---- H role ------------------------------------------------------------------------------------------------
-template <int AUX>
-__device__ __forceinline__ void store_own(const float (&pp)[16], __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned ld4) {
-    unsigned off = voff;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[e]), rs, off, 0, AUX);
-        off += ((e & 3) == 3) ? 5u * ld4 : ld4;
-    }
-}
 template <int AUX>
 __device__ __forceinline__ void store_five(const float (&p5)[4], __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned ld4) {
     unsigned off = voff;
