@@ -332,6 +332,20 @@ int rtk_rank_metrics_scaled_f64(const int32_t *ranks, const double *bce_rows, in
                                 double *acc5, void *stream);
 
 /*
+ * Kernel timer: the duration of ONE score-kernel launch as the device saw it -- begin and end of the kernel itself, the
+ * figure a rocprofv3 kernel trace reports -- without a profiler.  (A pair of events recorded on the stream around a
+ * launch also carries the event records' own stream time and the dispatch gap in front of the kernel: 2.5-3 us of a
+ * 31 us kernel.)  rtk_timer_arm(t): the NEXT score kernel this thread launches through rtk_score_packed_* /
+ * rtk_score_1vN_* (the column-group, wave-specialised and bf16 kernels; not the v3 split kernel or the exact-fp32 GEMM: there the timer reports an error) is launched
+ * with the timer's two events (hipExtLaunchKernelGGL); rtk_timer_elapsed_ms waits for that kernel and returns its
+ * duration.  Arming is per thread and consumed by one launch.  bench.py's roofline.kernel_ms.
+ */
+int rtk_timer_create(void **timer);
+int rtk_timer_arm(void *timer);
+int rtk_timer_elapsed_ms(void *timer, float *ms);
+int rtk_timer_destroy(void *timer);
+
+/*
  * Training forward with the loss fused into the score kernel's epilogue (reference train.py:79,136:
  * nn.BCELoss(mean) of sigmoid scores against label-smoothed targets y = (1 - eps) multi_hot + eps / N,
  * src/data/Dataset.py:51-52).  fp32 operands, c <= 512, packed query planes from rtk_query_vectors_f32.

@@ -69,6 +69,10 @@ SIGNATURES = {
     "rtk_comm_init": (_i, [_i, _i, _p, C.POINTER(_p)]),
     "rtk_allgather_scores": (_i, [_p, _p, _sz, _p]),
     "rtk_comm_destroy": (_i, [_p]),
+    "rtk_timer_create": (_i, [C.POINTER(C.c_void_p)]),
+    "rtk_timer_arm": (_i, [_p]),
+    "rtk_timer_elapsed_ms": (_i, [_p, C.POINTER(C.c_float)]),
+    "rtk_timer_destroy": (_i, [_p]),
     "rtk_gram_factor_f64": (_i, [_p, _i64, _i, _i, C.c_double, C.c_double, _p, _p, _p]),
     "rtk_target_scores_f32": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p]),
     "rtk_filtered_rank_partial_f32": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -223,7 +223,57 @@ extern "C" int rtk_query_vectors_from_tables_part_bf16(const float *tables, int6
                                      carve_ft(workspace, batch, n_rel), (hipStream_t)stream, part, n_parts);
 }
 
-extern "C" int rtk_version(void) { return 210; }
+// ---- kernel timer ------------------------------------------------------------------------------------------
+namespace {
+struct RtkTimer { hipEvent_t ev[2]; };
+thread_local RtkTimer *g_armed = nullptr;
+}  // namespace
+bool rtk_take_launch_events(hipEvent_t *start, hipEvent_t *stop) {
+    RtkTimer *t = g_armed;
+    if (!t) return false;
+    g_armed = nullptr;
+    *start = t->ev[0];
+    *stop = t->ev[1];
+    return true;
+}
+extern "C" int rtk_timer_create(void **timer) {
+    RTK_REQUIRE(timer, RTK_ERR_BAD_ARG, "rtk_timer_create: null argument");
+    RtkTimer *t = new RtkTimer{};
+    if (hipEventCreate(&t->ev[0]) != hipSuccess || hipEventCreate(&t->ev[1]) != hipSuccess) {
+        delete t;
+        rtk_set_error("rtk_timer_create: hipEventCreate failed");
+        return RTK_ERR_LAUNCH;
+    }
+    *timer = t;
+    return RTK_OK;
+}
+extern "C" int rtk_timer_arm(void *timer) {
+    RTK_REQUIRE(timer, RTK_ERR_BAD_ARG, "rtk_timer_arm: null timer");
+    g_armed = (RtkTimer *)timer;
+    return RTK_OK;
+}
+extern "C" int rtk_timer_elapsed_ms(void *timer, float *ms) {
+    RTK_REQUIRE(timer && ms, RTK_ERR_BAD_ARG, "rtk_timer_elapsed_ms: null argument");
+    RtkTimer *t = (RtkTimer *)timer;
+    hipError_t e = hipEventSynchronize(t->ev[1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, t->ev[0], t->ev[1]);
+    if (e != hipSuccess) {
+        rtk_set_error("rtk_timer_elapsed_ms: %s (was a score kernel launched after rtk_timer_arm?)", hipGetErrorString(e));
+        return RTK_ERR_LAUNCH;
+    }
+    return RTK_OK;
+}
+extern "C" int rtk_timer_destroy(void *timer) {
+    RTK_REQUIRE(timer, RTK_ERR_BAD_ARG, "rtk_timer_destroy: null timer");
+    RtkTimer *t = (RtkTimer *)timer;
+    if (g_armed == t) g_armed = nullptr;
+    (void)hipEventDestroy(t->ev[0]);
+    (void)hipEventDestroy(t->ev[1]);
+    delete t;
+    return RTK_OK;
+}
+
+extern "C" int rtk_version(void) { return 211; }
 extern "C" const char *rtk_last_error_string(void) { return g_err; }
 
 extern "C" size_t rtk_workspace_bytes(int dtype, int64_t batch, int64_t n_rel, int a, int b, int c) {

@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of librtucker_hip.so (internal header).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -24,6 +25,19 @@ void rtk_set_error(const char *fmt, ...);
             rtk_set_error(__VA_ARGS__);         \
             return (code);                      \
         }                                       \
+    } while (0)
+
+// Kernel timer (rtk_timer_*, rtk_abi.hip): a score-kernel launcher asks whether the calling thread armed a timer; if so
+// the launch goes through hipExtLaunchKernelGGL with the timer's two events, which the runtime stamps with the kernel's
+// own begin / end times (what a rocprofv3 kernel trace reports), not with the stream's progress around the launch.
+bool rtk_take_launch_events(hipEvent_t *start, hipEvent_t *stop);
+#define RTK_LAUNCH_SCORE(kernel, grid, block, smem, st, ...)                                                      \
+    do {                                                                                                          \
+        hipEvent_t ev0_, ev1_;                                                                                    \
+        if (rtk_take_launch_events(&ev0_, &ev1_))                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, st, ev0_, ev1_, 0, __VA_ARGS__);                     \
+        else                                                                                                      \
+            hipLaunchKernelGGL(kernel, grid, block, smem, st, __VA_ARGS__);                                       \
     } while (0)
 
 static inline int rtk_check_launch(const char *what) {

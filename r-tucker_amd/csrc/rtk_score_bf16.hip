@@ -347,7 +347,7 @@ int launch_nt(const unsigned char *qp, int B, const rtk_bf16 *O, int N, int c, f
     else qb = (int)rtk_cdiv(n_mt, rtk_cdiv(n_mt, qb));   // equal blocks
     const int64_t units = rtk_cdiv(N, 32 * NW) * (int64_t)qb;
     const unsigned grid = (unsigned)(units < 256 * MINW ? units : 256 * MINW);
-    hipLaunchKernelGGL((score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF, V2>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
+    RTK_LAUNCH_SCORE((score_bf16_kernel<KS, SG, MINW, NW, NTS, OBF, V2>), dim3(grid), dim3(64 * NW), smem, st, qp, B, O, N, c, out, ld, o_vec, qb);
     return RTK_OK;
 }
 

@@ -18,7 +18,7 @@ bool launch_v(const unsigned char *qp, int B, const float *O, int N, int c, floa
     static const int xcd_remap = getenv("RTK_WS_XCD") ? atoi(getenv("RTK_WS_XCD")) : 2;   // A/B: XCD-aware schedule (0 off, 1 both phases, 2 remainder tiles only)
     static const int nt_env = getenv("RTK_WS_NT") ? atoi(getenv("RTK_WS_NT")) : 1;   // A/B: nontemporal score stores
     const int nts = nt_env && (ld * 4) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
-    hipLaunchKernelGGL((rtk_ws::score_ws_kernel<KS, SG, OV>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld,
+    RTK_LAUNCH_SCORE((rtk_ws::score_ws_kernel<KS, SG, OV>), dim3(grid), dim3(512), smem, st, qp, B, O, N, c, out, ld,
                        xcd_remap, nts);
     return true;
 }

@@ -57,6 +57,9 @@ def test_argument_validation_returns_codes(lib):
     assert rc == -2 and b"workspace" in lib.rtk_last_error_string()
     rc = lib.rtk_gemm_f32(1, 1, 4, 1, 1, 4, 1, 2, 4, 4, 4, 0, null)
     assert rc == -1 and b"ldc" in lib.rtk_last_error_string()
+    # kernel timer: null handles are argument errors (creating one needs a device)
+    assert lib.rtk_timer_arm(null) == -1 and lib.rtk_timer_destroy(null) == -1
+    assert lib.rtk_timer_elapsed_ms(null, null) == -1 and lib.rtk_timer_create(null) == -1
 
 
 def test_cpu_tensors_are_rejected_loudly():
