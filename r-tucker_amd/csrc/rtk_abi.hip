@@ -225,13 +225,14 @@ extern "C" int rtk_query_vectors_from_tables_part_bf16(const float *tables, int6
 
 // ---- kernel timer ------------------------------------------------------------------------------------------
 namespace {
-struct RtkTimer { hipEvent_t ev[2]; };
+struct RtkTimer { hipEvent_t ev[2]; bool launched; };
 thread_local RtkTimer *g_armed = nullptr;
 }  // namespace
 bool rtk_take_launch_events(hipEvent_t *start, hipEvent_t *stop) {
     RtkTimer *t = g_armed;
     if (!t) return false;
     g_armed = nullptr;
+    t->launched = true;
     *start = t->ev[0];
     *stop = t->ev[1];
     return true;
@@ -250,15 +251,18 @@ extern "C" int rtk_timer_create(void **timer) {
 extern "C" int rtk_timer_arm(void *timer) {
     RTK_REQUIRE(timer, RTK_ERR_BAD_ARG, "rtk_timer_arm: null timer");
     g_armed = (RtkTimer *)timer;
+    g_armed->launched = false;
     return RTK_OK;
 }
 extern "C" int rtk_timer_elapsed_ms(void *timer, float *ms) {
     RTK_REQUIRE(timer && ms, RTK_ERR_BAD_ARG, "rtk_timer_elapsed_ms: null argument");
     RtkTimer *t = (RtkTimer *)timer;
+    RTK_REQUIRE(t->launched, RTK_ERR_BAD_ARG, "rtk_timer_elapsed_ms: no score kernel was launched on this timer (rtk_timer_arm, then a score call of the same thread)");
     hipError_t e = hipEventSynchronize(t->ev[1]);
     if (e == hipSuccess) e = hipEventElapsedTime(ms, t->ev[0], t->ev[1]);
     if (e != hipSuccess) {
-        rtk_set_error("rtk_timer_elapsed_ms: %s (was a score kernel launched after rtk_timer_arm?)", hipGetErrorString(e));
+        (void)hipGetLastError();            // (not left behind for the caller's next HIP call to trip over)
+        rtk_set_error("rtk_timer_elapsed_ms: %s", hipGetErrorString(e));
         return RTK_ERR_LAUNCH;
     }
     return RTK_OK;
