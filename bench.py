@@ -25,8 +25,10 @@ parameters only -- once: `--tables cached` rebuilds them every EVAL_BATCHES step
 the N = 1 line carries that figure as the extra key `cached_tables_ms_per_step`.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline`
-for the dominant kernel (the score kernel, timed with HIP events on its own stream
-inside the timed region) and `cpu_baseline` (the oracle's restatement of the reference
+for the dominant kernel (the score kernel: `kernel_ms` = its own begin -> end on HIP events
+handed to the launch, rtk_timer_* of the C ABI, on steps right behind the timed region;
+`stream_bracket_ms` = HIP events recorded on its stream around the launch inside the timed
+region) and `cpu_baseline` (the oracle's restatement of the reference
 op sequence timed on the host cores; N = 1 only).
 """
 from __future__ import annotations
