@@ -338,7 +338,9 @@ int rtk_rank_metrics_scaled_f64(const int32_t *ranks, const double *bce_rows, in
  * 31 us kernel.)  rtk_timer_arm(t): the NEXT score kernel this thread launches through rtk_score_packed_* /
  * rtk_score_1vN_* (the column-group, wave-specialised and bf16 kernels; not the v3 split kernel or the exact-fp32 GEMM: there the timer reports an error) is launched
  * with the timer's two events (hipExtLaunchKernelGGL); rtk_timer_elapsed_ms waits for that kernel and returns its
- * duration.  Arming is per thread and consumed by one launch.  bench.py's roofline.kernel_ms.
+ * duration.  Arming is per thread and consumed by one launch -- arm it directly in front of the stage-2 call
+ * (rtk_score_packed_*): with bf16 operands and a relation rank above 32 stage 1 builds its tables on the same bf16
+ * kernel and would take the timer.  bench.py's roofline.kernel_ms.
  */
 int rtk_timer_create(void **timer);
 int rtk_timer_arm(void *timer);
