@@ -69,7 +69,11 @@ int rtk_score_cg_launch(const unsigned char *qp, int B, const float *O, int N, i
     const int ks = (c + 15) / 16;
     if (!o_vec || ks > 13) return 0;   // c % 4 != 0 or unaligned O: the two-workgroup kernel has the scalar paths
     const int64_t G = rtk_cdiv(N, 32);
-    const int64_t sets_min = rtk_cdiv(G, rtk_cg::NG);
+    int64_t sets_min = rtk_cdiv(G, rtk_cg::NG);
+    // (A/B, RTK_CG_SPREAD=1: a shape with fewer than 256 full sets is spread over min(G, 256) workgroups of 1-4 groups
+    // instead of ceil(G / 5) workgroups of five)
+    static const int spread = getenv("RTK_CG_SPREAD") ? atoi(getenv("RTK_CG_SPREAD")) : 0;
+    if (spread && sets_min < 256) sets_min = G < 256 ? G : 256;
     const int W = (int)(sets_min < 256 ? sets_min : 256);
     const int64_t P = rtk_cdiv(sets_min, W);
     if (P * W > (1 << 30)) return 0;
