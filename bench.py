@@ -70,10 +70,8 @@ def score_kernel_name(n_loc, c):
         return "score_split_kernel"
     if forced.startswith("ws"):
         return "score_ws_kernel"
-    from r_tucker_amd.ops import cg_fifth_group_columns
     G = -(-n_loc // 32)
-    sets_min = -(-G // 5)
-    on_cg = forced.startswith("cg") or (sets_min == 256 and 10 * G >= 44 * 256)
+    on_cg = forced.startswith("cg") or 576 <= G <= 1280      # one set per workgroup, at least two groups in it
     return "score_cg_kernel" if on_cg else "score_ws_kernel"
 
 

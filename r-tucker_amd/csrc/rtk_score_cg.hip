@@ -57,27 +57,25 @@ extern "C" int rtk_cg_timeline(unsigned long long *dst, int n, int clear) {
 #endif
 
 // The set schedule: G = ceil(N/32) column groups in U = W * P sets of <= 5 consecutive groups, P sets per
-// workgroup (one after the other).  `force`: run this kernel whatever the shape (tests, A/B).
-// Chosen by default only where it is the better schedule: one set per workgroup (P = 1) and at least ~4.4
-// groups in it on a full grid -- the four M waves all busy, the fifth group filling most sets -- i.e.
-// 36 000 < N <= 40 960 on 256 CUs (WN18RR: 40 943 entities = 1280 groups = 5 per CU exactly).  Shallower or
-// deeper shapes keep the ws kernel's tile schedule (several passes here would each pay an exposed load of
-// the next set).
+// workgroup (one after the other): ceil(G / 5) sets when that fills the chip, else min(G, 256) sets of 1-5 groups
+// (all CUs busy; up to 1024 groups no set has a fifth group and every score has the ws kernel's bits).
+// `force`: run this kernel whatever the shape (tests, A/B).  Chosen by default for one set per workgroup (P = 1)
+// with at least two groups in it: 18 432 <= N <= 40 960 on 256 CUs (tools/ab_cg_shapes.py, c = 200, B = 512, back to
+// back: N = 20 000 22.3 us against 24.5 for the ws kernel, 26 000 25.0 / 28.8, 32 000 25.9 / 32.7, 36 000 31-33 / 40,
+// 40 943 (WN18RR: 1280 groups = 5 per CU exactly) 32-34 / 36-41; at 14 951 the two tie, at 16 384 (the ws kernel's tiles divide evenly) it is 10 % ahead, from 46 000 on -- two
+// passes here, each with its own exposed prologue -- the ws kernel's tile schedule is 1-10 % ahead).
 // 1 = launched, 0 = not this kernel's shape (the caller goes on to the next kernel), < 0 = rtk_status
 int rtk_score_cg_launch(const unsigned char *qp, int B, const float *O, int N, int c, float *out, int64_t ld,
                         int sg, bool o_vec, bool force, hipStream_t st) {
     const int ks = (c + 15) / 16;
     if (!o_vec || ks > 13) return 0;   // c % 4 != 0 or unaligned O: the two-workgroup kernel has the scalar paths
     const int64_t G = rtk_cdiv(N, 32);
-    int64_t sets_min = rtk_cdiv(G, rtk_cg::NG);
-    // (A/B, RTK_CG_SPREAD=1: a shape with fewer than 256 full sets is spread over min(G, 256) workgroups of 1-4 groups
-    // instead of ceil(G / 5) workgroups of five)
-    static const int spread = getenv("RTK_CG_SPREAD") ? atoi(getenv("RTK_CG_SPREAD")) : 0;
-    if (spread && sets_min < 256) sets_min = G < 256 ? G : 256;
-    const int W = (int)(sets_min < 256 ? sets_min : 256);
-    const int64_t P = rtk_cdiv(sets_min, W);
+    int64_t sets = rtk_cdiv(G, rtk_cg::NG);
+    if (sets < 256) sets = G < 256 ? G : 256;
+    const int W = (int)(sets < 256 ? sets : 256);
+    const int64_t P = rtk_cdiv(sets, W);
     if (P * W > (1 << 30)) return 0;
-    if (!force && !(P == 1 && W == 256 && 10 * G >= 44 * W)) return 0;
+    if (!force && !(P == 1 && G >= 576)) return 0;
     const int U = (int)(P * W);
     if (sg == 0) return rtk_score_cg_launch_sg0(ks, qp, B, O, N, c, out, ld, W, U, st);
     if (sg == 1) return rtk_score_cg_launch_sg1(ks, qp, B, O, N, c, out, ld, W, U, st);

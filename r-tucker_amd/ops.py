@@ -700,16 +700,19 @@ def score_packed_into(qp, B, O, out, sigmoid=True, sigmoid_mode=None):
 def cg_fifth_group_columns(N, c, n_cu=256):
     """Boolean mask (N,) of the entity columns that the default fp32 score kernel computes as FOUR K-range chains added
     in a fixed order instead of one chain -- the fifth column group of a workgroup's set in the column-group kernel
-    (csrc/rtk_score_cg.hip: chosen for one set per workgroup on a full grid, 36 000 < N <= 40 960 on 256 CUs, c <= 208,
-    c % 4 == 0).  Everywhere else (all False for other shapes) a score does not depend on how many other entities are
-    scored with it; on these columns an entity-sharded run and a single-device run differ in the last bits."""
+    (csrc/rtk_score_cg.hip: chosen for one set per workgroup, 18 432 <= N <= 40 960 on 256 CUs, c <= 208, c % 4 == 0;
+    a set has a fifth group only above 1024 groups, N > 32 768).  Everywhere else (all False) a score does not depend
+    on how many other entities are scored with it; on these columns an entity-sharded run and a single-device run
+    differ in the last bits."""
     import numpy as np
     mask = np.zeros(N, dtype=bool)
     G = -(-N // 32)
-    sets_min = -(-G // 5)
-    W = min(n_cu, sets_min)
-    P = -(-sets_min // W)
-    if c > 208 or c % 4 or not (P == 1 and W == n_cu and 10 * G >= 44 * W):
+    sets = -(-G // 5)
+    if sets < n_cu:
+        sets = min(G, n_cu)
+    W = min(n_cu, sets)
+    P = -(-sets // W)
+    if c > 208 or c % 4 or not (P == 1 and G >= 576):
         return mask
     U = W * P
     for u in range(U):

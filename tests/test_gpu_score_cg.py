@@ -46,9 +46,11 @@ def _score(rt, qp, B, O, flags, pitch=None, fill=None):
 def _fifth_group_columns(N, W_max=256):
     """columns that the cg schedule puts into a set's fifth (K-split) group"""
     G = -(-N // 32)
-    sets_min = -(-G // 5)
-    W = min(W_max, sets_min)
-    U = W * -(-sets_min // W)
+    sets = -(-G // 5)
+    if sets < W_max:
+        sets = min(G, W_max)
+    W = min(W_max, sets)
+    U = W * -(-sets // W)
     fifth = np.zeros(N, dtype=bool)
     for u in range(U):
         gb, ge = G * u // U, G * (u + 1) // U
@@ -58,16 +60,18 @@ def _fifth_group_columns(N, W_max=256):
 
 
 SHAPES = [
-    # (N, c, B, pitch)                      what it exercises
+    # (N, c, B, pitch)                      what it exercises (sets: ceil(G / 5) of them when that fills 256 workgroups,
+    #                                       else min(G, 256) sets of 1-5 groups)
     (40943, 200, 512, 40960),             # the bench workload: 1280 groups = 5 per workgroup, nontemporal stores
     (40943, 200, 500, None),              # dense rows (plain stores), ragged last query tile
-    (2000, 200, 64, None),                # 63 groups in 13 sets of 4 and 5
+    (20000, 200, 64, None),               # 625 groups in 256 sets of 2 and 3 (one or two M waves without a group)
+    (36000, 64, 40, None),                # 1125 groups in 256 sets of 4 and 5: sets with and without a fifth group side by side
+    (2000, 200, 64, None),                # 63 groups, one per workgroup
     (333, 36, 70, None),                  # KS = 3: two M waves have an empty k-range; N % 32 != 0
-    (100, 4, 5, None),                    # KS = 1, one set of four groups, last group 4 columns wide
+    (100, 4, 5, None),                    # KS = 1, last group 4 columns wide
     (20, 8, 33, None),                    # fewer entities than one group
-    (167, 208, 96, 192),                  # KS = 13 at the widest c: 6 groups in two sets of three (two M waves idle)
-    (160, 208, 64, None),                 # KS = 13 at the widest c: one set of exactly five groups (the LDS maximum)
-    (100000, 64, 40, None),               # 3125 groups: three sets per workgroup, one after the other
+    (167, 208, 96, 192),                  # KS = 13 at the widest c
+    (100000, 64, 40, None),               # 3125 groups: 768 sets of 4 and 5, three per workgroup, one after the other
     (5 * 32 * 256 + 1, 16, 32, None),     # one group more than a full single pass holds: two passes
 ]
 
@@ -111,16 +115,21 @@ def test_all_kernels_against_float64(rt, N, c, B, pitch):
 
 
 def test_default_dispatch_takes_cg_at_the_wn18rr_shape(rt):
-    """no hint: N = 40 943 (1280 groups on 256 workgroups) runs the cg kernel, N = 14 951 the ws kernel --
-    visible in the fifth-group columns, which are the only ones that differ between the two"""
+    """no hint: 18 432 <= N <= 40 960 runs the cg kernel (one set per workgroup), other shapes the ws kernel.  Visible
+    where a set has a fifth group (more than 1024 groups: N = 40 943) -- those columns are the only ones that differ
+    between the two; up to 1024 groups (N = 20 000, 14 951) the cg kernel has the ws kernel's bits everywhere."""
     g = torch.Generator().manual_seed(11)
     L = rt._lib
-    for N, expect_cg in ((40943, True), (14951, False)):
+    for N in (40943, 20000, 14951, 46000, 100000):
+        fifth = bool(_fifth_group_columns(N).any())
+        assert fifth == (N in (40943, 100000))
         v = torch.randn((64, 200), generator=g).cuda()
         O = torch.randn((N, 200), generator=g).cuda()
         qp = rt.pack_query_vectors(v, torch.float32)
         auto = _score(rt, qp, 64, O, 0).cpu().numpy()
         cg = _score(rt, qp, 64, O, L.RTK_SCORE_KERNEL_CG).cpu().numpy()
         ws = _score(rt, qp, 64, O, L.RTK_SCORE_KERNEL_WS).cpu().numpy()
-        assert not np.array_equal(cg, ws)           # (the fifth groups: different summation order)
-        assert np.array_equal(auto, cg if expect_cg else ws)
+        assert np.array_equal(cg, ws) == (not fifth)
+        assert np.array_equal(cg[:, ~_fifth_group_columns(N)], ws[:, ~_fifth_group_columns(N)])
+        assert np.array_equal(auto, ws if N > 40960 else cg)
+        assert bool(rt.ops.cg_fifth_group_columns(N, 200).any()) == (fifth and N <= 40960)
