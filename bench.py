@@ -433,8 +433,9 @@ def main():
         step(i)
     # HIP events bracket the score kernel on its stream on every 8th timed step (an event pair
     # costs a few us of stream time; sampling keeps the timed region representative); short runs
-    # (the driver's 20 steps) sample every 2nd step so that the average rests on ten brackets, not three
-    every = 8 if args.steps >= 200 else 2
+    # (the driver's 20 steps) sample every 4th step: five brackets -- `roofline.kernel_ms` no longer rests on them
+    # (the kernel timer behind the timed region does), they are the line's `stream_bracket_ms`
+    every = 8 if args.steps >= 200 else 4
     events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) if i % every == 0 else None
               for i in range(args.steps)]
     barrier()
