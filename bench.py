@@ -24,6 +24,10 @@ the same extract_tensor(model)), so an evaluation pass can build the tables -- a
 parameters only -- once: `--tables cached` rebuilds them every EVAL_BATCHES steps inside the timed region;
 the N = 1 line carries that figure as the extra key `cached_tables_ms_per_step`.
 
+The K timed steps are launched as ONE HIP graph in a short single-GPU run (`--launch auto`: K <= 256; captured before
+the timed region, launched once inside it) and one C-ABI call after the other otherwise; `config.launch` says which,
+`eager_ms_per_step` is the eager loop of the same K steps timed right behind the graph.
+
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline`
 for the dominant kernel (the score kernel: `kernel_ms` = its own begin -> end on HIP events
 handed to the launch, rtk_timer_* of the C ABI, on steps right behind the timed region;
@@ -214,6 +218,12 @@ def main():
                     help="N = 1, the one-GPU share of configs[4]: also time ONE rank's step of an N-rank run (stage 1 for the "
                          "relations of rank 0 only, pack, score the shard; no collective) -> emulated_per_gpu_ms_per_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="how the K timed steps reach the GPU: one HIP graph of the K steps captured beforehand and launched "
+                         "once inside the timed region, or one call into the C ABI after the other.  auto = graph for a "
+                         "single-GPU run of at most 256 steps (a 20-step region is 1 ms of GPU work: the host's launch "
+                         "pipeline filling and the event brackets are several per cent of it), eager otherwise; the eager "
+                         "figure of the same K steps is reported beside it (eager_ms_per_step)")
     ap.add_argument("--prewarm-ms", type=float, default=1000.0,
                     help="untimed clock ramp before the --warmup steps: the same steps for this long (a 20-step run is "
                          "over before the GPU leaves its idle clocks); reported as config.prewarm_ms")
@@ -306,7 +316,10 @@ def main():
     gathered, out = gathered_all[0], gathered_all[0][rank]
     pending = [None] * n_buf
 
-    stream = torch.cuda.current_stream(dev)
+    # everything runs on ONE side stream (the legacy default stream cannot be captured into a HIP graph: --launch graph)
+    torch.cuda.synchronize(dev)             # (the operands were created on the default stream)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     cached = args.tables == "cached"
     split1 = world > 1 and (args.stage1 in ("split", "relation") or (args.stage1 == "auto" and a > 32))
@@ -438,12 +451,37 @@ def main():
     every = 8 if args.steps >= 200 else 4
     events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) if i % every == 0 else None
               for i in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, events[i])
-    barrier()
-    dt = time.perf_counter() - t0
+    use_graph = args.launch == "graph" or (args.launch == "auto" and world == 1 and not use_dist and args.steps <= 256)
+    if use_graph and use_dist:
+        raise SystemExit("--launch graph: single-GPU runs only (the all-gather is not captured)")
+    eager_dt = None
+    if use_graph:
+        # The K steps as ONE HIP graph (the C ABI only enqueues on the given stream: capturable, tests/test_gpu_parity.py),
+        # captured and replayed once untimed, then launched once -- onto a drained stream -- between the two barriers.
+        # Same kernels, same operands, same order as the eager loop below, which is timed too.
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for i in range(args.steps):
+                step(args.warmup + i)
+        graph.replay()
+        barrier()
+        t0 = time.perf_counter()
+        graph.replay()
+        barrier()
+        dt = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, events[i])
+        barrier()
+        eager_dt = time.perf_counter() - t0
+    else:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, events[i])
+        barrier()
+        dt = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -600,12 +638,15 @@ def main():
                    "score_kernel": "exact_f32_mfma" if args.exact else ("bf16_mfma" if bf16 else "split_fp16_mfma"),
                    "sigmoid": "exact" if args.exact else sig_mode,
                    "prewarm_ms": args.prewarm_ms,
+                   "launch": ("one HIP graph of the %d steps, launched once inside the timed region" % args.steps) if use_graph
+                             else "eager: one C-ABI call after the other",
                    "relation_tables": (f"cached: rebuilt every {EVAL_BATCHES} steps inside the timed region" if cached
                                        else "rebuilt in every step"),
                    "stage1": ("split over ranks by relation id + all-reduce of the query vectors" if by_rel else
                               "batch split over ranks + all-gather of the query vectors" if split1 else "on every rank"),
                    "sharding": "none" if world == 1 else f"entity rows / {world} + RCCL all-gather"},
         "scores_per_s": args.steps * B * n_ent / dt,
+        **({"eager_ms_per_step": eager_dt / args.steps * 1e3} if eager_dt is not None else {}),
         **extras,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

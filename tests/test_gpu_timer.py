@@ -37,3 +37,30 @@ def test_timed_launch_gives_the_same_scores_and_a_duration_inside_the_stream_bra
     again = rt.score_1vN(core, R, S, O, h, r)                            # arming is consumed by one launch
     assert torch.equal(plain, again)
     L.check(lib.rtk_timer_destroy(timer), "rtk_timer_destroy")
+
+
+def test_bench_line_in_both_launch_modes():
+    """python bench.py: the K timed steps as one HIP graph (the default for short single-GPU runs) and eager -- one JSON
+    line each, the same metric, the kernel timer's figure inside the stream bracket's"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for mode in ("graph", "eager"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline",
+                              "--prewarm-ms", "200", "--launch", mode], capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(rows) == 1
+        lines[mode] = json.loads(rows[0])
+    g, e = lines["graph"], lines["eager"]
+    assert g["metric"] == e["metric"] and g["steps"] == e["steps"] == 12
+    assert "HIP graph" in g["config"]["launch"] and "eager" in e["config"]["launch"]
+    assert "eager_ms_per_step" in g and "eager_ms_per_step" not in e
+    for d in (g, e):
+        r = d["roofline"]
+        assert 0 < r["kernel_ms"] <= r["stream_bracket_ms"] * 1.05 and r["kernel_ms_source"].startswith("kernel begin/end")
+        assert abs(d["value"] - 12 * 512 / (d["ms_per_step"] * 12e-3)) < 1e-6 * d["value"]
+    assert g["ms_per_step"] < 1.5 * e["ms_per_step"] and e["ms_per_step"] < 1.5 * g["ms_per_step"]
