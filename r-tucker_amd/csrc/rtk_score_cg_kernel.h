@@ -358,7 +358,7 @@ __device__ __forceinline__ void m_sweep(const LdsMap &L, int cnt, int lane, cons
 
 template <int KS, int W4, int SIGMOID>
 __device__ __forceinline__ void m_role(const Geo &geo, const float *__restrict__ O, float *__restrict__ out,
-                                       const LdsMap &L, int lane, int t, int nts) {
+                                       const LdsMap &L, int lane, int nts) {
     constexpr int S0 = s_begin(KS, W4), S1 = s_end(KS, W4), NS = S1 - S0;
     const int r = lane & 31, h = lane >> 5, c = geo.c;
     const bool tl_on = W4 == 0 && lane == 0;
@@ -443,8 +443,7 @@ __device__ __forceinline__ void store_five(const float (&p5)[4], __amdgpu_buffer
 
 // Prologue of all four helper waves: query tile 0 (256 threads) -> buffer 0 and row-factor slot 0.
 template <int KS>
-__device__ __forceinline__ void h_prologue(const Geo &geo, const unsigned char *__restrict__ q_packed,
-                                           const float *__restrict__ O, const LdsMap &L, int gb, int n_g, int t) {
+__device__ __forceinline__ void h_prologue(const unsigned char *__restrict__ q_packed, const LdsMap &L, int t) {
     constexpr int TILE_BYTES = tile_bytes<KS>();
     constexpr int CHUNKS = TILE_BYTES / 16;
     constexpr int NLD = (CHUNKS + 255) / 256;
@@ -471,8 +470,7 @@ __device__ __forceinline__ void h_prologue(const Geo &geo, const unsigned char *
 // factors, tile i-1).  Wave SW takes the units u = SW, SW + 3, ...: 28 / 28 / 24 stores.
 template <int KS, int SIGMOID, int SW>
 __device__ __forceinline__ void s_role(const Geo &geo, const unsigned char *__restrict__ q_packed,
-                                       const float *__restrict__ O, float *__restrict__ out,
-                                       const LdsMap &L, int lane, int t, int nts, int tune) {
+                                       float *__restrict__ out, const LdsMap &L, int lane, int t, int nts, int tune) {
     constexpr int NU = (20 - SW + 2) / 3;        // units of this wave
     const int r = lane & 31, h = lane >> 5, N = geo.N, B = geo.B;
     const int64_t ld_out = geo.ld_out;
@@ -484,7 +482,7 @@ __device__ __forceinline__ void s_role(const Geo &geo, const unsigned char *__re
         int gb, n_g;
         geo.set(u, gb, n_g);
         RTK_CG_TL(1, 1);
-        h_prologue<KS>(geo, q_packed, O, L, gb, n_g, t);
+        h_prologue<KS>(q_packed, L, t);
         RTK_CG_TL(1, 2);
         const bool five = n_g == NG;
         __syncthreads();                             // P1
@@ -569,7 +567,7 @@ __device__ __forceinline__ void s_role(const Geo &geo, const unsigned char *__re
 // "L" role: the load wave
 template <int KS>
 __device__ __forceinline__ void l_role(const Geo &geo, const unsigned char *__restrict__ q_packed,
-                                       const float *__restrict__ O, const LdsMap &L, int lane, int t, int tune) {
+                                       const LdsMap &L, int lane, int t, int tune) {
     constexpr int TILE_BYTES = tile_bytes<KS>();
     constexpr int CHUNKS = TILE_BYTES / 16;
     constexpr int NLD = (CHUNKS + 63) / 64;     // staging 16-B chunks per lane
@@ -598,7 +596,7 @@ __device__ __forceinline__ void l_role(const Geo &geo, const unsigned char *__re
     for (int u = blockIdx.x; u < geo.U; u += gridDim.x) {
         int gb, n_g;
         geo.set(u, gb, n_g);
-        h_prologue<KS>(geo, q_packed, O, L, gb, n_g, t);
+        h_prologue<KS>(q_packed, L, t);
         if (cnt > 1 && !(tune & 32)) stage_load(1);  // in flight across the prologue's barriers
         __syncthreads();                             // P1
         __syncthreads();                             // P2
@@ -633,14 +631,14 @@ __global__ __launch_bounds__(512, 2) void score_cg_kernel(
         else if (pr == 2) __builtin_amdgcn_s_setprio(2);
         else if (pr == 3) __builtin_amdgcn_s_setprio(3);
     }
-    if (uwave == 0) m_role<KS, 0, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
-    else if (uwave == 1) m_role<KS, 1, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
-    else if (uwave == 2) m_role<KS, 2, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
-    else if (uwave == 3) m_role<KS, 3, SIGMOID>(geo, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts));
-    else if (uwave == 4) s_role<KS, SIGMOID, 0>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
-    else if (uwave == 5) s_role<KS, SIGMOID, 1>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
-    else if (uwave == 6) s_role<KS, SIGMOID, 2>(geo, q_packed, O, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
-    else l_role<KS>(geo, q_packed, O, L, lane, t, __builtin_amdgcn_readfirstlane(tune));
+    if (uwave == 0) m_role<KS, 0, SIGMOID>(geo, O, out, L, lane, __builtin_amdgcn_readfirstlane(nts));
+    else if (uwave == 1) m_role<KS, 1, SIGMOID>(geo, O, out, L, lane, __builtin_amdgcn_readfirstlane(nts));
+    else if (uwave == 2) m_role<KS, 2, SIGMOID>(geo, O, out, L, lane, __builtin_amdgcn_readfirstlane(nts));
+    else if (uwave == 3) m_role<KS, 3, SIGMOID>(geo, O, out, L, lane, __builtin_amdgcn_readfirstlane(nts));
+    else if (uwave == 4) s_role<KS, SIGMOID, 0>(geo, q_packed, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
+    else if (uwave == 5) s_role<KS, SIGMOID, 1>(geo, q_packed, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
+    else if (uwave == 6) s_role<KS, SIGMOID, 2>(geo, q_packed, out, L, lane, t, __builtin_amdgcn_readfirstlane(nts), __builtin_amdgcn_readfirstlane(tune));
+    else l_role<KS>(geo, q_packed, L, lane, t, __builtin_amdgcn_readfirstlane(tune));
 }
 
 }  // namespace rtk_cg
