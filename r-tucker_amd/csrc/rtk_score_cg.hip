@@ -18,7 +18,8 @@ bool launch_v(const unsigned char *qp, int B, const float *O, int N, int c, floa
     static const int nt_env = getenv("RTK_WS_NT") ? atoi(getenv("RTK_WS_NT")) : 1;   // A/B: nontemporal score stores
     const int nts = nt_env && (ld * 4) % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0;
     static const int tune = getenv("RTK_CG_TUNE") ? atoi(getenv("RTK_CG_TUNE")) : 0;   // A/B: wave priorities
-    RTK_LAUNCH_SCORE((rtk_cg::score_cg_kernel<KS, SG>), dim3(W), dim3(512), smem, st, qp, B, O, N, c, out, ld, U, nts, tune);
+    RTK_LAUNCH_SCORE((rtk_cg::score_cg_kernel<KS, SG>), dim3(W), dim3(512), smem, st, qp, B, O, N, c, out, ld, U,
+                     (int)(rtk_cdiv(N, 32) / U), (int)(rtk_cdiv(N, 32) % U), nts, tune);
     return true;
 }
 

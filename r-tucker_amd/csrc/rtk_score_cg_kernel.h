@@ -90,12 +90,18 @@ __host__ __device__ constexpr int s_end(int KS, int w) { return (KS * (w + 1) + 
 
 struct Geo {
     int B, N, c, U, n_mt;
+    int gq, gr;              // G / U and G % U (G = ceil(N / 32) groups), from the host
     int64_t ld_out;
-    // set u of U: groups [gb, gb + n_g), n_g <= NG
+    // set u of U: groups [gb, gb + n_g), n_g <= NG;  gb = floor(G u / U) = gq u + floor(gr u / U).
+    // (G u / U in 64 bits cost every wave two ~500-cycle divisions in front of its first load; with gr < U <= 32 768 --
+    // any launch of up to 128 sets per workgroup -- the remainders fit 32 bits.)
+    __device__ __forceinline__ int first_group(int u) const {
+        if (U <= 32768) return gq * u + (int)((unsigned)(gr * u) / (unsigned)U);
+        return (int)((((int64_t)gq * U + gr) * u) / U);
+    }
     __device__ __forceinline__ void set(int u, int &gb, int &n_g) const {
-        const int64_t G = ((int64_t)N + 31) / 32;
-        gb = (int)(G * u / U);
-        n_g = (int)(G * (u + 1) / U) - gb;
+        gb = first_group(u);
+        n_g = first_group(u + 1) - gb;
     }
 };
 
@@ -614,13 +620,13 @@ __device__ __forceinline__ void l_role(const Geo &geo, const unsigned char *__re
 template <int KS, int SIGMOID>
 __global__ __launch_bounds__(512, 2) void score_cg_kernel(
     const unsigned char *__restrict__ q_packed, int B, const float *__restrict__ O, int N, int c,
-    float *__restrict__ out, int64_t ld_out, int U, int nts, int tune) {
+    float *__restrict__ out, int64_t ld_out, int U, int gq, int gr, int nts, int tune) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     LdsMap L;
     L.init<KS>(lds);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     Geo geo;
-    geo.B = B; geo.N = N; geo.c = c; geo.U = U; geo.n_mt = (B + 31) / 32; geo.ld_out = ld_out;
+    geo.B = B; geo.N = N; geo.c = c; geo.U = U; geo.gq = gq; geo.gr = gr; geo.n_mt = (B + 31) / 32; geo.ld_out = ld_out;
     // wave-uniform role split (readfirstlane makes the uniformity visible to the compiler); one instantiation
     // of the M role per wave: the fifth group's k-range, and with it the gap schedule, is static
     const int uwave = __builtin_amdgcn_readfirstlane(wave);

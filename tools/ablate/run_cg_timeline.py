@@ -69,6 +69,10 @@ cn = np.array([tm[w, 0, (code[w, 0, :] == 13).argmax() - 1] for w in range(256)]
 print(f"in-kernel: {np.median(rtn - rt0) / 100:.2f} us of 100 MHz ticks, {np.median(cn - c0):.0f} shader cycles -> clock {np.median((cn - c0) / np.maximum(rtn - rt0, 1)) * 0.1:.3f} GHz")
 tm[:, 0, :-1] = tm[:, 0, 1:]          # drop the realtime stamp at the head of M wave 0's list
 code[:, 0, :-1] = code[:, 0, 1:]
+# the two roles' clocks against each other: s_memtime of M wave 0's first stamp minus S wave 0's, per workgroup (a wave
+# reaches its first stamp when the code of its role has been fetched)
+print(f"M wave 0 start - S wave 0 start (cycles): median {np.median(tm[:, 0, 0] - tm[:, 1, 0]):.0f}  "
+      f"[p10 {np.percentile(tm[:, 0, 0] - tm[:, 1, 0], 10):.0f} .. p90 {np.percentile(tm[:, 0, 0] - tm[:, 1, 0], 90):.0f}]")
 for role, name in ((0, "M wave 0"), (1, "S wave 0")):
     n_ev = int(((code[:, role, :] != 0) & (code[:, role, :] != 13)).sum(axis=1).min())
     t0 = tm[:, role, 0:1]
