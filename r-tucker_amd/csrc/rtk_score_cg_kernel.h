@@ -637,6 +637,11 @@ __global__ __launch_bounds__(512, 2) void score_cg_kernel(
         else if (pr == 2) __builtin_amdgcn_s_setprio(2);
         else if (pr == 3) __builtin_amdgcn_s_setprio(3);
     }
+#ifdef RTK_CG_STAMPS
+    // (slot 63 of a role's list: s_memtime in the kernel's common entry code, in front of the branch to the role)
+    if ((uwave == 0 || uwave == 4) && lane == 0)
+        g_cg_tl[(blockIdx.x * 2 + (uwave >> 2)) * 64 + 63] = __builtin_amdgcn_s_memtime();
+#endif
     if (uwave == 0) m_role<KS, 0, SIGMOID>(geo, O, out, L, lane, __builtin_amdgcn_readfirstlane(nts));
     else if (uwave == 1) m_role<KS, 1, SIGMOID>(geo, O, out, L, lane, __builtin_amdgcn_readfirstlane(nts));
     else if (uwave == 2) m_role<KS, 2, SIGMOID>(geo, O, out, L, lane, __builtin_amdgcn_readfirstlane(nts));

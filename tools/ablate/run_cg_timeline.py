@@ -73,6 +73,12 @@ code[:, 0, :-1] = code[:, 0, 1:]
 # reaches its first stamp when the code of its role has been fetched)
 print(f"M wave 0 start - S wave 0 start (cycles): median {np.median(tm[:, 0, 0] - tm[:, 1, 0]):.0f}  "
       f"[p10 {np.percentile(tm[:, 0, 0] - tm[:, 1, 0], 10):.0f} .. p90 {np.percentile(tm[:, 0, 0] - tm[:, 1, 0], 90):.0f}]")
+raw63 = tl[:, :, 63].astype(np.int64)
+if raw63 is not None and raw63.min() > 0:
+    for role, name in ((0, "M wave 0"), (1, "S wave 0")):
+        d = tm[:, role, 0] - raw63[:, role]
+        print(f"{name}: kernel entry -> first stamp of the role: median {np.median(d):.0f} cycles [p10 {np.percentile(d, 10):.0f} .. p90 {np.percentile(d, 90):.0f}]")
+    print(f"entry of M wave 0 - entry of S wave 0: median {np.median(raw63[:, 0] - raw63[:, 1]):.0f} cycles")
 for role, name in ((0, "M wave 0"), (1, "S wave 0")):
     n_ev = int(((code[:, role, :] != 0) & (code[:, role, :] != 13)).sum(axis=1).min())
     t0 = tm[:, role, 0:1]
