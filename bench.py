@@ -460,10 +460,18 @@ def main():
         # captured and replayed once untimed, then launched once -- onto a drained stream -- between the two barriers.
         # Same kernels, same operands, same order as the eager loop below, which is timed too.
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            for i in range(args.steps):
-                step(args.warmup + i)
-        graph.replay()
+        try:
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(args.steps):
+                    step(args.warmup + i)
+            graph.replay()
+        except Exception as e:               # (--launch auto must not cost the line: fall back to the eager loop)
+            if args.launch == "graph":
+                raise
+            print(f"bench.py: HIP graph capture failed ({e!r}); timing the eager loop", file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize(dev)
+    if use_graph:
         barrier()
         t0 = time.perf_counter()
         graph.replay()
